@@ -1,0 +1,198 @@
+// az_device.h -- device-side helpers for the gfx950 self-play engine.
+//
+// Everything here is written for CDNA4 only (64-wide wavefronts, no portability shims).
+// Floating-point helpers are the engine's "canonical" forms: fixed sequences of IEEE
+// operations (fma chains, correctly rounded divides) so that results do not depend on a
+// vendor libm.  Build with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define AZ_WAVE 64
+
+// ---------------------------------------------------------------------------------------
+// canonical math (same operation sequence as the reference restatement used for testing)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float az_expf(float x)
+{
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    float t = x * 1.44269504088896341f;
+    float kf = __builtin_rintf(t);
+    float r = __builtin_fmaf(kf, -0.693145751953125f, x);
+    r = __builtin_fmaf(kf, -1.42860682030941723212e-6f, r);
+    float p = 1.0f / 5040.0f;
+    p = __builtin_fmaf(p, r, 1.0f / 720.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 120.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 24.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 6.0f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    int k = (int)kf;
+    return p * __uint_as_float((unsigned)(k + 127) << 23);
+}
+
+__device__ __forceinline__ float az_tanhf(float x)
+{
+    float a = __builtin_fabsf(x);
+    float t = az_expf(-2.0f * a);
+    float r = (1.0f - t) / (1.0f + t);
+    return x < 0.0f ? -r : r;
+}
+
+__device__ __forceinline__ double az_exp(double x)
+{
+    if (x < -708.0) return 0.0;
+    if (x > 709.0) x = 709.0;
+    double kf = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(kf, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = __builtin_fma(p, r, 1.0 / 479001600.0);
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    long long k = (long long)kf;
+    return p * __longlong_as_double((long long)((u64)(k + 1023) << 52));
+}
+
+__device__ __forceinline__ unsigned az_fmix32(unsigned x)
+{
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+
+// ---------------------------------------------------------------------------------------
+// wave-level reductions (64 lanes).  Butterfly order is part of the canonical definition.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum_butterfly(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max_d(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        double o = __shfl_xor(v, m, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_xor_u(unsigned v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = v ^ (unsigned)__shfl_xor((int)v, m, 64);
+    return v;
+}
+// argmax with first-index tie-break: max score, then min index (mcts.py:71 "first maximal child")
+__device__ __forceinline__ void wave_argmax(double &s, int &idx)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        double os = __shfl_xor(s, m, 64);
+        int oi = __shfl_xor(idx, m, 64);
+        bool take = (oi >= 0) && (idx < 0 || os > s || (os == s && oi < idx));
+        s = take ? os : s;
+        idx = take ? oi : idx;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// bit-planed boards: 4 x u64 per plane (n*n <= 225 bits), cell j -> word j>>6, bit j&63
+// ---------------------------------------------------------------------------------------
+struct Plane {
+    u64 w[4];
+};
+__device__ __forceinline__ bool pl_get(const Plane &p, int j)
+{
+    int wi = j >> 6;
+    u64 v = wi == 0 ? p.w[0] : wi == 1 ? p.w[1] : wi == 2 ? p.w[2] : p.w[3];
+    return (v >> (j & 63)) & 1ull;
+}
+__device__ __forceinline__ void pl_set(Plane &p, int j)
+{
+    int wi = j >> 6;
+    u64 b = 1ull << (j & 63);
+    p.w[0] |= wi == 0 ? b : 0ull;
+    p.w[1] |= wi == 1 ? b : 0ull;
+    p.w[2] |= wi == 2 ? b : 0ull;
+    p.w[3] |= wi == 3 ? b : 0ull;
+}
+__device__ __forceinline__ int pl_count(const Plane &p)
+{
+    return __popcll(p.w[0]) + __popcll(p.w[1]) + __popcll(p.w[2]) + __popcll(p.w[3]);
+}
+// number of set bits strictly below position j
+__device__ __forceinline__ int pl_rank(const Plane &p, int j)
+{
+    int wi = j >> 6;
+    u64 mask = (1ull << (j & 63)) - 1ull;
+    int c = 0;
+    c += wi > 0 ? __popcll(p.w[0]) : (wi == 0 ? __popcll(p.w[0] & mask) : 0);
+    c += wi > 1 ? __popcll(p.w[1]) : (wi == 1 ? __popcll(p.w[1] & mask) : 0);
+    c += wi > 2 ? __popcll(p.w[2]) : (wi == 2 ? __popcll(p.w[2] & mask) : 0);
+    c += wi == 3 ? __popcll(p.w[3] & mask) : 0;
+    return c;
+}
+__device__ __forceinline__ Plane pl_load(const u64 *g)
+{
+    Plane p;
+    p.w[0] = g[0]; p.w[1] = g[1]; p.w[2] = g[2]; p.w[3] = g[3];
+    return p;
+}
+__device__ __forceinline__ void pl_store(u64 *g, const Plane &p)
+{
+    g[0] = p.w[0]; g[1] = p.w[1]; g[2] = p.w[2]; g[3] = p.w[3];
+}
+
+// games.py:133-166 restricted to lines through the stone just placed at cell a of plane `me`
+// (any new run of >= k must contain it; overlines count, games.py:212-227).
+__device__ __forceinline__ bool wins_through(const Plane &me, int a, int n, int k)
+{
+    int r = a / n, c = a - r * n;
+    const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 0, 1, -1};
+    bool win = false;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        int cnt = 1;
+        for (int s = 1; s < k; s++) {
+            int rr = r + s * dr[d], cc = c + s * dc[d];
+            if (rr < 0 || rr >= n || cc < 0 || cc >= n || !pl_get(me, rr * n + cc)) break;
+            cnt++;
+        }
+        for (int s = 1; s < k; s++) {
+            int rr = r - s * dr[d], cc = c - s * dc[d];
+            if (rr < 0 || rr >= n || cc < 0 || cc >= n || !pl_get(me, rr * n + cc)) break;
+            cnt++;
+        }
+        win = win || (cnt >= k);
+    }
+    return win;
+}

@@ -1,0 +1,864 @@
+// az_engine.hip -- host side of the C-ABI (include/az_engine.h): device memory, weight packing into
+// MFMA fragment order, the lock-step episode loop (root eval -> S x {net, expand/backup/select} -> move),
+// record export.  gfx950 only; there is no CPU implementation of the path in this library.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/az_engine.h"
+#include "az_net.h"
+
+namespace azrng {
+void selfplay_tapes_parallel(uint64_t seed0, int g0, int count, int nn, double alpha, int max_plies, double *noise,
+                             int64_t noise_stride, double *u, int threads);
+void uniforms(uint64_t seed, int count, double *u);
+}
+
+static thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct PackedNet {
+    bool loaded = false;
+    DevBuf c1, c2, c3, hd, pf, vf, c1b, c2b, c3b, hdb, pfb, vfb, v2w, v2b;
+    NetWeights w{};
+};
+
+struct az_engine {
+    az_config cfg{};
+    int n = 0, nn = 0, RW = 0, R = 0, PATH = 0;
+    std::string err;
+    hipStream_t stream = nullptr;
+    DevState d{};
+    std::vector<DevBuf *> owned;
+    // per-engine buffers
+    DevBuf board, s_game, s_ply, s_player, s_last, s_status, s_net, edges, rows_used, path, depth, leaf_kind, leaf,
+        leaf_last, logits, vhid, pol_feat, val_feat, T_table, log_table, sqrt_table, noise_off, cnt, next_game, active;
+    // per-episode buffers
+    DevBuf noise, u, rec_planes, rec_last, rec_action, rec_mover, rec_pi, rec_visits, g_nply, g_result, src_index;
+    int episode_games = 0, episode_capacity = 0;
+    int64_t tape_len = 0;          // doubles per game in the noise tape
+    bool have_episode = false;
+    std::vector<int> h_nply, h_result;
+    PackedNet net[2];
+    az_counters last{};
+    // profiling events
+    std::vector<hipEvent_t> ev;
+    bool profile = true;
+};
+
+// ------------------------------------------------------------------------------------------------
+static int fail(az_engine *e, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (e) e->err = buf; else g_create_error = buf;
+    return code;
+}
+#define HIPCHECK(e, call)                                                                          \
+    do {                                                                                           \
+        hipError_t _r = (call);                                                                    \
+        if (_r != hipSuccess)                                                                      \
+            return fail(e, AZ_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+
+static int dev_alloc(az_engine *e, DevBuf &b, size_t bytes, bool zero = true)
+{
+    if (b.p && b.bytes >= bytes) {
+        if (zero) HIPCHECK(e, hipMemsetAsync(b.p, 0, bytes, e->stream));
+        return AZ_OK;
+    }
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+    if (bytes == 0) bytes = 16;
+    HIPCHECK(e, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    if (zero) HIPCHECK(e, hipMemsetAsync(b.p, 0, bytes, e->stream));
+    return AZ_OK;
+}
+static void dev_free(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+static int upload(az_engine *e, DevBuf &b, const void *src, size_t bytes)
+{
+    int rc = dev_alloc(e, b, bytes, false);
+    if (rc) return rc;
+    HIPCHECK(e, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, e->stream));
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    return AZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: B-operand fragments of v_mfma_f32_16x16x4_f32.  Lane l supplies B[k = l>>4][j = l&15]
+// of k-step s; four consecutive k-steps are stored together so one dwordx4 load feeds four MFMAs:
+//   packed[((ntile*KS4 + s/4)*64 + lane)*4 + s%4]
+// ------------------------------------------------------------------------------------------------
+static std::vector<float> pack_conv(const float *w, int cout, int cin)
+{
+    // torch [co][ci][ky][kx]; k-step s = tap*(cin/4) + s', ci = 4*s' + (lane>>4)
+    const int kst = cin / 4, ks = 9 * kst, ks4 = (ks + 3) / 4, nt = cout / 16;
+    std::vector<float> out((size_t)nt * ks4 * 64 * 4, 0.0f);
+    for (int t = 0; t < nt; t++)
+        for (int s = 0; s < ks; s++)
+            for (int lane = 0; lane < 64; lane++) {
+                int tap = s / kst, sp = s % kst;
+                int ci = 4 * sp + (lane >> 4), co = t * 16 + (lane & 15);
+                out[(((size_t)t * ks4 + s / 4) * 64 + lane) * 4 + (s % 4)] = w[((size_t)co * cin + ci) * 9 + tap];
+            }
+    return out;
+}
+static std::vector<float> pack_heads(const float *pw, const float *vw)
+{
+    // policy_conv [4][128], value_conv [2][128] -> one 16-column tile, 32 k-steps
+    std::vector<float> out((size_t)8 * 64 * 4, 0.0f);
+    for (int s = 0; s < 32; s++)
+        for (int lane = 0; lane < 64; lane++) {
+            int ci = 4 * s + (lane >> 4), j = lane & 15;
+            float v = j < 4 ? pw[j * 128 + ci] : (j < 6 ? vw[(j - 4) * 128 + ci] : 0.0f);
+            out[(((size_t)s / 4) * 64 + lane) * 4 + (s % 4)] = v;
+        }
+    return out;
+}
+static std::vector<float> pack_fc(const float *w, int nout, int kin)
+{
+    // torch Linear [out][in]; tile t covers outputs 16t..16t+15; k-step s covers k = 4s..4s+3
+    const int nt = (nout + 15) / 16, ks = (kin + 3) / 4, ks4 = (ks + 3) / 4;
+    std::vector<float> out((size_t)nt * ks4 * 64 * 4, 0.0f);
+    for (int t = 0; t < nt; t++)
+        for (int s = 0; s < ks; s++)
+            for (int lane = 0; lane < 64; lane++) {
+                int k = 4 * s + (lane >> 4), j = t * 16 + (lane & 15);
+                float v = (j < nout && k < kin) ? w[(size_t)j * kin + k] : 0.0f;
+                out[(((size_t)t * ks4 + s / 4) * 64 + lane) * 4 + (s % 4)] = v;
+            }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel dispatch by board size
+// ------------------------------------------------------------------------------------------------
+template <int N>
+static void launch_net(az_engine *e, int net_id)
+{
+    typedef NetGeo<N> G;
+    const int B = e->d.B;
+    dim3 gt((B + G::G - 1) / G::G), bt(512);
+    hipLaunchKernelGGL(k_trunk<N>, gt, bt, 0, e->stream, e->d, e->net[net_id].w, net_id, (float *)e->pol_feat.p,
+                       (float *)e->val_feat.p);
+    dim3 gf((B + 15) / 16, G::NSPLIT), bf(256);
+    hipLaunchKernelGGL(k_fc<N>, gf, bf, 0, e->stream, e->d, e->net[net_id].w, net_id, (const float *)e->pol_feat.p,
+                       (const float *)e->val_feat.p);
+}
+template <int N>
+static void launch_trunk_only(az_engine *e, int net_id)
+{
+    typedef NetGeo<N> G;
+    dim3 gt((e->d.B + G::G - 1) / G::G), bt(512);
+    hipLaunchKernelGGL(k_trunk<N>, gt, bt, 0, e->stream, e->d, e->net[net_id].w, net_id, (float *)e->pol_feat.p,
+                       (float *)e->val_feat.p);
+}
+template <int N>
+static void launch_fc_only(az_engine *e, int net_id)
+{
+    typedef NetGeo<N> G;
+    dim3 gf((e->d.B + 15) / 16, G::NSPLIT), bf(256);
+    hipLaunchKernelGGL(k_fc<N>, gf, bf, 0, e->stream, e->d, e->net[net_id].w, net_id, (const float *)e->pol_feat.p,
+                       (const float *)e->val_feat.p);
+}
+template <int N>
+static void launch_step(az_engine *e, int rootN, int do_select)
+{
+    dim3 g((e->d.B + 3) / 4), b(256);
+    if (e->cfg.eval_kind == AZ_EVAL_SYNTHETIC)
+        hipLaunchKernelGGL((k_step<N, true>), g, b, 0, e->stream, e->d, rootN, do_select);
+    else
+        hipLaunchKernelGGL((k_step<N, false>), g, b, 0, e->stream, e->d, rootN, do_select);
+}
+template <int N>
+static void launch_move(az_engine *e)
+{
+    dim3 g((e->d.B + 3) / 4), b(256);
+    hipLaunchKernelGGL(k_move<N>, g, b, 0, e->stream, e->d);
+}
+template <int N>
+static void launch_eval_tail(az_engine *e, int count, float *pol, float *val)
+{
+    dim3 g((count + 3) / 4), b(256);
+    hipLaunchKernelGGL(k_eval_tail<N>, g, b, 0, e->stream, e->d, count, pol, val);
+}
+
+#define DISPATCH_N(e, fn, ...)                                   \
+    do {                                                         \
+        if ((e)->n == 5) fn<5>(__VA_ARGS__);                     \
+        else if ((e)->n == 9) fn<9>(__VA_ARGS__);                \
+        else fn<15>(__VA_ARGS__);                                \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// packed records + examples (self_play.py:94-108 augmentation fused into the encode)
+// record layout: [8 x u64 planes (mover, opponent)] [pi f32 x nn] [last i16] [mover u8] [z i8], padded to 8 B
+// ------------------------------------------------------------------------------------------------
+static inline int64_t record_bytes(int nn) { return ((64 + 4 * (int64_t)nn + 4) + 7) / 8 * 8; }
+
+__global__ void k_pack(DevState d, const int *src_index, int64_t records, int nn, int64_t rb, unsigned char *out)
+{
+    int64_t r = blockIdx.x;
+    if (r >= records) return;
+    int si = src_index[r];
+    int g = si / nn;
+    unsigned char *o = out + r * rb;
+    u64 *op = reinterpret_cast<u64 *>(o);
+    float *opi = reinterpret_cast<float *>(o + 64);
+    if (threadIdx.x < 8) op[threadIdx.x] = d.rec_planes[(size_t)si * 8 + threadIdx.x];
+    for (int j = threadIdx.x; j < nn; j += blockDim.x) opi[j] = d.rec_pi[(size_t)si * nn + j];
+    if (threadIdx.x == 0) {
+        short *ol = reinterpret_cast<short *>(o + 64 + 4 * nn);
+        ol[0] = d.rec_last[si];
+        int mover = d.rec_mover[si], res = d.g_result[g];
+        o[64 + 4 * nn + 2] = (unsigned char)mover;
+        // self_play.py:71: 0 if draw, +1 if the mover won, -1 otherwise; 99 marks a game cut by max_plies
+        reinterpret_cast<signed char *>(o)[64 + 4 * nn + 3] = (signed char)(res == 0 ? 99 : (res == 3 ? 0 : (mover == res ? 1 : -1)));
+    }
+}
+
+// source cell of output cell (i, j) under symmetry k of the dihedral group: k<4 = np.rot90 k times (CCW),
+// k>=4 = rot90(fliplr(x), k-4)
+__device__ __forceinline__ int sym_src(int k, int i, int j, int n)
+{
+    int si, sj;
+    switch (k & 3) {
+    case 0: si = i; sj = j; break;
+    case 1: si = j; sj = n - 1 - i; break;
+    case 2: si = n - 1 - i; sj = n - 1 - j; break;
+    default: si = n - 1 - j; sj = i; break;
+    }
+    if (k >= 4) sj = n - 1 - sj;
+    return si * n + sj;
+}
+
+__global__ void k_examples(const unsigned char *packed, int64_t records, int n, int64_t rb, int aug, float *states,
+                           float *pis, float *zs)
+{
+    const int nn = n * n;
+    int64_t r = blockIdx.x;
+    if (r >= records) return;
+    const unsigned char *o = packed + r * rb;
+    const u64 *pl = reinterpret_cast<const u64 *>(o);
+    const float *pi = reinterpret_cast<const float *>(o + 64);
+    const int last = reinterpret_cast<const short *>(o + 64 + 4 * nn)[0];
+    const int z = reinterpret_cast<const signed char *>(o)[64 + 4 * nn + 3];
+    for (int k = 0; k < aug; k++) {
+        float *so = states + ((size_t)r * aug + k) * 4 * nn;
+        float *po = pis + ((size_t)r * aug + k) * nn;
+        for (int c = threadIdx.x; c < nn; c += blockDim.x) {
+            int i = c / n, j = c - i * n;
+            int src = sym_src(k, i, j, n);
+            so[c] = ((pl[src >> 6] >> (src & 63)) & 1ull) ? 1.0f : 0.0f;            // games.py:117-124
+            so[nn + c] = ((pl[4 + (src >> 6)] >> (src & 63)) & 1ull) ? 1.0f : 0.0f;
+            so[2 * nn + c] = (src == last) ? 1.0f : 0.0f;                              // games.py:126-128
+            so[3 * nn + c] = 0.0f;
+            // reference mode (aug == 4): pi is rotated exactly once for every k (self_play.py:105)
+            int psrc = aug == AZ_AUG_REFERENCE4 ? sym_src(1, i, j, n) : src;
+            po[c] = pi[psrc];
+        }
+        if (threadIdx.x == 0) zs[(size_t)r * aug + k] = (float)z;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// lifecycle
+// ------------------------------------------------------------------------------------------------
+extern "C" const char *az_last_error(const az_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+static int setup_tables(az_engine *e)
+{
+    const int S = e->cfg.num_simulations, nn = e->nn;
+    std::vector<float> lt(S + 2);
+    for (int i = 0; i <= S + 1; i++) lt[i] = e->cfg.log_table && i <= S ? e->cfg.log_table[i] : logf((float)i + 1e-8f);
+    std::vector<double> st(S + 3);
+    for (int i = 0; i <= S + 2; i++) st[i] = std::sqrt((double)i + 1e-8);
+    std::vector<int> no(nn + 2);
+    int off = 0;
+    for (int m = 0; m <= nn; m++) { no[m] = off; off += nn - m; }
+    e->tape_len = off;
+    int rc;
+    if ((rc = upload(e, e->log_table, lt.data(), lt.size() * sizeof(float)))) return rc;
+    if ((rc = upload(e, e->sqrt_table, st.data(), st.size() * sizeof(double)))) return rc;
+    if ((rc = upload(e, e->noise_off, no.data(), no.size() * sizeof(int)))) return rc;
+    return AZ_OK;
+}
+
+extern "C" int az_create(const az_config *cfg, az_engine **out)
+{
+    if (!cfg || !out) return fail(nullptr, AZ_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->board_size != 5 && cfg->board_size != 9 && cfg->board_size != 15)
+        return fail(nullptr, AZ_ERR_INVALID, "board_size must be 5, 9 or 15 (got %d)", cfg->board_size);
+    if (cfg->win_length < 2 || cfg->win_length > cfg->board_size) return fail(nullptr, AZ_ERR_INVALID, "bad win_length");
+    if (cfg->num_simulations < 1 || cfg->num_simulations > 1024) return fail(nullptr, AZ_ERR_INVALID, "num_simulations must be 1..1024");
+    if (cfg->slots < 1 || cfg->slots > 65536) return fail(nullptr, AZ_ERR_INVALID, "slots must be 1..65536");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, AZ_ERR_NO_DEVICE, "no HIP device: this engine has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, AZ_ERR_INVALID, "device %d out of range (%d devices)", cfg->device, ndev);
+    az_engine *e = new az_engine();
+    e->cfg = *cfg;
+    e->n = cfg->board_size;
+    e->nn = e->n * e->n;
+    e->RW = (e->nn + 63) / 64 * 64;
+    e->R = cfg->num_simulations + 1;
+    e->PATH = e->nn + 1;
+    hipError_t hr = hipSetDevice(cfg->device);
+    if (hr == hipSuccess) hr = hipStreamCreate(&e->stream);
+    if (hr != hipSuccess) {
+        int rc = fail(nullptr, AZ_ERR_HIP, "device init failed: %s", hipGetErrorString(hr));
+        delete e;
+        return rc;
+    }
+    const size_t B = (size_t)cfg->slots;
+    int rc = AZ_OK;
+#define ALLOC(buf, bytes) if (!rc) rc = dev_alloc(e, e->buf, (bytes))
+    ALLOC(board, B * 8 * sizeof(u64));
+    ALLOC(s_game, B * 4); ALLOC(s_ply, B * 4); ALLOC(s_player, B * 4); ALLOC(s_last, B * 4);
+    ALLOC(s_status, B * 4); ALLOC(s_net, B * 4);
+    ALLOC(edges, B * (size_t)e->R * e->RW * sizeof(Edge));
+    ALLOC(rows_used, B * 4); ALLOC(path, B * (size_t)e->PATH * 4); ALLOC(depth, B * 4);
+    ALLOC(leaf_kind, B * 4); ALLOC(leaf, B * 8 * sizeof(u64)); ALLOC(leaf_last, B * 4);
+    ALLOC(logits, B * (size_t)e->RW * 4); ALLOC(vhid, B * 64 * 4);
+    ALLOC(pol_feat, B * (size_t)4 * e->nn * 4); ALLOC(val_feat, B * (size_t)2 * e->nn * 4);
+    ALLOC(cnt, B * 4 * sizeof(unsigned long long)); ALLOC(next_game, 16); ALLOC(active, 16);
+    ALLOC(T_table, (size_t)(e->nn + 4) * sizeof(double));
+#undef ALLOC
+    if (!rc) rc = setup_tables(e);
+    if (rc) {
+        g_create_error = e->err;
+        az_destroy(e);
+        return rc;
+    }
+    DevState &d = e->d;
+    d.B = cfg->slots; d.R = e->R; d.S = cfg->num_simulations; d.k = cfg->win_length;
+    d.c_puct = cfg->c_puct; d.w_noise = cfg->dirichlet_weight;
+    d.one_minus_w = (float)(1.0 - cfg->dirichlet_weight);   // Python float (1 - w) as a weak scalar -> float32 (Q8)
+    d.board = (u64 *)e->board.p;
+    d.s_game = (int *)e->s_game.p; d.s_ply = (int *)e->s_ply.p; d.s_player = (int *)e->s_player.p;
+    d.s_last = (int *)e->s_last.p; d.s_status = (int *)e->s_status.p; d.s_net = (int *)e->s_net.p;
+    d.edges = (Edge *)e->edges.p; d.rows_used = (int *)e->rows_used.p; d.path = (unsigned *)e->path.p;
+    d.depth = (int *)e->depth.p; d.leaf_kind = (int *)e->leaf_kind.p; d.leaf = (u64 *)e->leaf.p;
+    d.leaf_last = (int *)e->leaf_last.p; d.logits = (float *)e->logits.p; d.vhid = (float *)e->vhid.p;
+    d.T_table = (const double *)e->T_table.p; d.log_table = (const float *)e->log_table.p;
+    d.sqrt_table = (const double *)e->sqrt_table.p; d.noise_off = (const int *)e->noise_off.p;
+    d.cnt = (unsigned long long *)e->cnt.p; d.next_game = (int *)e->next_game.p; d.active = (int *)e->active.p;
+    d.v2w[0] = d.v2w[1] = d.v2b[0] = d.v2b[1] = nullptr;
+    const char *pe = getenv("AZ_PROFILE_EVENTS");
+    e->profile = !(pe && pe[0] == '0');
+    if (hipStreamSynchronize(e->stream) != hipSuccess) {
+        g_create_error = "stream sync failed in az_create";
+        az_destroy(e);
+        return AZ_ERR_HIP;
+    }
+    *out = e;
+    return AZ_OK;
+}
+
+extern "C" void az_destroy(az_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    DevBuf *all[] = {&e->board, &e->s_game, &e->s_ply, &e->s_player, &e->s_last, &e->s_status, &e->s_net, &e->edges,
+                     &e->rows_used, &e->path, &e->depth, &e->leaf_kind, &e->leaf, &e->leaf_last, &e->logits, &e->vhid,
+                     &e->pol_feat, &e->val_feat, &e->T_table, &e->log_table, &e->sqrt_table, &e->noise_off, &e->cnt,
+                     &e->next_game, &e->active, &e->noise, &e->u, &e->rec_planes, &e->rec_last, &e->rec_action,
+                     &e->rec_mover, &e->rec_pi, &e->rec_visits, &e->g_nply, &e->g_result, &e->src_index};
+    for (DevBuf *b : all) dev_free(*b);
+    for (int s = 0; s < 2; s++) {
+        PackedNet &p = e->net[s];
+        DevBuf *nb[] = {&p.c1, &p.c2, &p.c3, &p.hd, &p.pf, &p.vf, &p.c1b, &p.c2b, &p.c3b, &p.hdb, &p.pfb, &p.vfb, &p.v2w, &p.v2b};
+        for (DevBuf *b : nb) dev_free(*b);
+    }
+    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" int az_load_weights(az_engine *e, int slot, const float *const *t)
+{
+    if (!e || !t || slot < 0 || slot > 1) return fail(e, AZ_ERR_INVALID, "az_load_weights: bad argument");
+    for (int i = 0; i < 16; i++)
+        if (!t[i]) return fail(e, AZ_ERR_INVALID, "az_load_weights: tensor %d is null", i);
+    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    const int nn = e->nn;
+    PackedNet &p = e->net[slot];
+    int rc = AZ_OK;
+    auto up = [&](DevBuf &b, const std::vector<float> &v) { if (!rc) rc = upload(e, b, v.data(), v.size() * sizeof(float)); };
+    auto upraw = [&](DevBuf &b, const float *v, size_t cnt) { if (!rc) rc = upload(e, b, v, cnt * sizeof(float)); };
+    up(p.c1, pack_conv(t[0], 32, 4));   upraw(p.c1b, t[1], 32);
+    up(p.c2, pack_conv(t[2], 64, 32));  upraw(p.c2b, t[3], 64);
+    up(p.c3, pack_conv(t[4], 128, 64)); upraw(p.c3b, t[5], 128);
+    up(p.hd, pack_heads(t[6], t[10]));
+    float hb[6] = {t[7][0], t[7][1], t[7][2], t[7][3], t[11][0], t[11][1]};
+    upraw(p.hdb, hb, 6);
+    up(p.pf, pack_fc(t[8], nn, 4 * nn));  upraw(p.pfb, t[9], nn);
+    up(p.vf, pack_fc(t[12], 64, 2 * nn)); upraw(p.vfb, t[13], 64);
+    upraw(p.v2w, t[14], 64); upraw(p.v2b, t[15], 1);
+    if (rc) return rc;
+    p.w.c1 = (const float *)p.c1.p; p.w.c2 = (const float *)p.c2.p; p.w.c3 = (const float *)p.c3.p;
+    p.w.hd = (const float *)p.hd.p; p.w.pf = (const float *)p.pf.p; p.w.vf = (const float *)p.vf.p;
+    p.w.c1b = (const float *)p.c1b.p; p.w.c2b = (const float *)p.c2b.p; p.w.c3b = (const float *)p.c3b.p;
+    p.w.hdb = (const float *)p.hdb.p; p.w.pfb = (const float *)p.pfb.p; p.w.vfb = (const float *)p.vfb.p;
+    e->d.v2w[slot] = (const float *)p.v2w.p;
+    e->d.v2b[slot] = (const float *)p.v2b.p;
+    p.loaded = true;
+    return AZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// episode machinery
+// ------------------------------------------------------------------------------------------------
+static int ensure_episode_buffers(az_engine *e, int games, bool need_noise)
+{
+    const size_t nn = e->nn, G = (size_t)games;
+    int rc = AZ_OK;
+#define ALLOC(buf, bytes, zero) if (!rc) rc = dev_alloc(e, e->buf, (bytes), zero)
+    ALLOC(rec_planes, G * nn * 8 * sizeof(u64), false);
+    ALLOC(rec_last, G * nn * 2, false); ALLOC(rec_action, G * nn * 2, false); ALLOC(rec_mover, G * nn, false);
+    ALLOC(rec_pi, G * nn * nn * 4, false); ALLOC(rec_visits, G * nn * nn * 2, false);
+    ALLOC(g_nply, G * 4, true); ALLOC(g_result, G * 4, true);
+    ALLOC(u, G * nn * sizeof(double), false);
+    if (need_noise) ALLOC(noise, G * (size_t)e->tape_len * sizeof(double), false);
+#undef ALLOC
+    if (rc) return rc;
+    DevState &d = e->d;
+    d.rec_planes = (u64 *)e->rec_planes.p; d.rec_last = (short *)e->rec_last.p; d.rec_action = (short *)e->rec_action.p;
+    d.rec_mover = (unsigned char *)e->rec_mover.p; d.rec_pi = (float *)e->rec_pi.p;
+    d.rec_visits = (unsigned short *)e->rec_visits.p; d.g_nply = (int *)e->g_nply.p; d.g_result = (int *)e->g_result.p;
+    d.u = (const double *)e->u.p; d.noise = (const double *)e->noise.p; d.noise_stride = e->tape_len;
+    return AZ_OK;
+}
+
+struct EpisodeSpec {
+    int num_games = 0, max_plies = 0;
+    bool add_noise = true, arena = false;
+    bool preset = false;      // slot 0 already holds a position (az_search); skip the initial refill
+    bool profile = true;
+};
+
+static int host_threads()
+{
+    unsigned hc = std::thread::hardware_concurrency();
+    int t = hc ? (int)hc : 4;
+    const char *ev = getenv("AZ_HOST_THREADS");
+    if (ev) t = atoi(ev);
+    return t < 1 ? 1 : (t > 64 ? 64 : t);
+}
+
+static int run_episode(az_engine *e, const EpisodeSpec &sp, az_counters *out)
+{
+    DevState &d = e->d;
+    const int S = d.S;
+    const bool net = e->cfg.eval_kind == AZ_EVAL_NET;
+    if (net && !e->net[0].loaded) return fail(e, AZ_ERR_NO_WEIGHTS, "weights slot 0 not loaded");
+    if (net && sp.arena && !e->net[1].loaded) return fail(e, AZ_ERR_NO_WEIGHTS, "weights slot 1 (baseline) not loaded");
+    d.max_plies = sp.max_plies; d.add_noise = sp.add_noise ? 1 : 0; d.arena = sp.arena ? 1 : 0;
+    d.total_games = sp.num_games;
+    HIPCHECK(e, hipMemsetAsync(e->cnt.p, 0, e->cnt.bytes, e->stream));
+    if (!sp.preset) {
+        HIPCHECK(e, hipMemsetAsync(e->s_status.p, 0, e->s_status.bytes, e->stream));
+        HIPCHECK(e, hipMemsetAsync(e->next_game.p, 0, 16, e->stream));
+        hipLaunchKernelGGL(k_refill, dim3(1), dim3(1024), 0, e->stream, d);
+    }
+    // events for the net kernels: pairs (trunk start, trunk end, fc end) per evaluation of one ply
+    const bool prof = net && sp.profile && e->profile;
+    const size_t need_ev = prof ? (size_t)3 * (S + 1) : 0;
+    while (e->ev.size() < need_ev) {
+        hipEvent_t ev;
+        HIPCHECK(e, hipEventCreate(&ev));
+        e->ev.push_back(ev);
+    }
+    az_counters c{};
+    int active = sp.preset ? 1 : 0;
+    if (!sp.preset) {
+        HIPCHECK(e, hipMemcpyAsync(&active, e->active.p, 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHECK(e, hipStreamSynchronize(e->stream));
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    double trunk_ms = 0.0, nn_ms = 0.0;
+    const int nnets = sp.arena ? 2 : 1;
+    while (active > 0) {
+        hipLaunchKernelGGL(k_begin, dim3((d.B + 255) / 256), dim3(256), 0, e->stream, d);
+        for (int t = -1; t < S; t++) {
+            if (net) {
+                const int ei = 3 * (t + 1);
+                if (prof) HIPCHECK(e, hipEventRecord(e->ev[ei], e->stream));
+                for (int id = 0; id < nnets; id++) DISPATCH_N(e, launch_trunk_only, e, id);
+                if (prof) HIPCHECK(e, hipEventRecord(e->ev[ei + 1], e->stream));
+                for (int id = 0; id < nnets; id++) DISPATCH_N(e, launch_fc_only, e, id);
+                if (prof) HIPCHECK(e, hipEventRecord(e->ev[ei + 2], e->stream));
+                c.trunk_launches += nnets;
+            }
+            // t = -1 consumes the root evaluation (root N = 0 for the first selection); t >= 0 consumes simulation t
+            DISPATCH_N(e, launch_step, e, t + 1, (t + 1 < S) ? 1 : 0);
+            c.steps++;
+        }
+        DISPATCH_N(e, launch_move, e);
+        c.trunk_boards += (int64_t)active * (S + 1);
+        if (sp.preset) {
+            active = 0;
+        } else {
+            hipLaunchKernelGGL(k_refill, dim3(1), dim3(1024), 0, e->stream, d);
+            HIPCHECK(e, hipMemcpyAsync(&active, e->active.p, 4, hipMemcpyDeviceToHost, e->stream));
+        }
+        HIPCHECK(e, hipStreamSynchronize(e->stream));
+        HIPCHECK(e, hipGetLastError());
+        if (prof) {
+            for (int i = 0; i <= S; i++) {
+                float a = 0.f, b = 0.f;
+                HIPCHECK(e, hipEventElapsedTime(&a, e->ev[3 * i], e->ev[3 * i + 1]));
+                HIPCHECK(e, hipEventElapsedTime(&b, e->ev[3 * i + 1], e->ev[3 * i + 2]));
+                trunk_ms += a;
+                nn_ms += a + b;
+            }
+        }
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    c.seconds = std::chrono::duration<double>(t1 - t0).count();
+    c.trunk_seconds = trunk_ms * 1e-3;
+    c.nn_seconds = nn_ms * 1e-3;
+    // gather counters
+    std::vector<unsigned long long> hc((size_t)d.B * 4);
+    HIPCHECK(e, hipMemcpy(hc.data(), e->cnt.p, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int b = 0; b < d.B; b++) {
+        c.expansions += (int64_t)hc[(size_t)b * 4 + 0];
+        c.simulations += (int64_t)hc[(size_t)b * 4 + 1];
+        c.terminal_hits += (int64_t)hc[(size_t)b * 4 + 2];
+        c.depth_sum += (int64_t)hc[(size_t)b * 4 + 3];
+    }
+    e->h_nply.assign(sp.num_games, 0);
+    e->h_result.assign(sp.num_games, 0);
+    HIPCHECK(e, hipMemcpy(e->h_nply.data(), e->g_nply.p, (size_t)sp.num_games * 4, hipMemcpyDeviceToHost));
+    HIPCHECK(e, hipMemcpy(e->h_result.data(), e->g_result.p, (size_t)sp.num_games * 4, hipMemcpyDeviceToHost));
+    if (sp.preset) {
+        // az_search plays exactly one ply; the game itself is not finished by it
+        int ply1 = 0;
+        HIPCHECK(e, hipMemcpy(&ply1, e->s_ply.p, 4, hipMemcpyDeviceToHost));
+        e->h_nply[0] = 1;
+    }
+    c.games = sp.num_games;
+    for (int g = 0; g < sp.num_games; g++) c.plies += e->h_nply[g];
+    c.records = c.plies;
+    c.root_evals = c.plies;
+    e->last = c;
+    e->episode_games = sp.num_games;
+    e->have_episode = true;
+    if (out) *out = c;
+    return AZ_OK;
+}
+
+static int upload_T(az_engine *e, const double *table, bool arena)
+{
+    const int nn = e->nn;
+    std::vector<double> T(nn + 4);
+    for (int m = 0; m < nn + 4; m++) {
+        if (table && m <= nn) T[m] = table[m];
+        else T[m] = arena ? 0.3 * std::exp(-(double)m / 4.0) : (std::exp(-(double)m / 100.0) + 0.01) / 1.01;
+    }
+    HIPCHECK(e, hipMemcpyAsync(e->T_table.p, T.data(), T.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    return AZ_OK;
+}
+
+extern "C" int az_selfplay(az_engine *e, const az_selfplay_args *a, az_counters *out)
+{
+    if (!e || !a || a->num_games < 1) return fail(e, AZ_ERR_INVALID, "az_selfplay: bad argument");
+    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    const int nn = e->nn, G = a->num_games;
+    int rc = ensure_episode_buffers(e, G, true);
+    if (rc) return rc;
+    if ((rc = upload_T(e, a->temperature_table, false))) return rc;
+    // tapes: explicit, or numpy-compatible RandomState(seed0 + g) streams generated on the host cores
+    const int plies = a->max_plies > 0 && a->max_plies < nn ? a->max_plies : nn;
+    if (a->noise_tape && a->u_tape) {
+        if (a->tape_stride < e->tape_len && a->max_plies <= 0) return fail(e, AZ_ERR_INVALID, "tape_stride too small");
+        HIPCHECK(e, hipMemcpy2DAsync(e->noise.p, (size_t)e->tape_len * 8, a->noise_tape, (size_t)a->tape_stride * 8,
+                                     (size_t)std::min<int64_t>(a->tape_stride, e->tape_len) * 8, G, hipMemcpyHostToDevice, e->stream));
+        HIPCHECK(e, hipMemcpyAsync(e->u.p, a->u_tape, (size_t)G * nn * 8, hipMemcpyHostToDevice, e->stream));
+        HIPCHECK(e, hipStreamSynchronize(e->stream));
+    } else {
+        const int chunk = 256;
+        std::vector<double> hn((size_t)chunk * e->tape_len), hu((size_t)chunk * nn);
+        for (int g0 = 0; g0 < G; g0 += chunk) {
+            int cnt = std::min(chunk, G - g0);
+            azrng::selfplay_tapes_parallel(a->seed0, g0, cnt, nn, e->cfg.dirichlet_alpha, plies, hn.data(), e->tape_len,
+                                           hu.data(), host_threads());
+            HIPCHECK(e, hipMemcpy((double *)e->noise.p + (size_t)g0 * e->tape_len, hn.data(), (size_t)cnt * e->tape_len * 8,
+                                  hipMemcpyHostToDevice));
+            HIPCHECK(e, hipMemcpy((double *)e->u.p + (size_t)g0 * nn, hu.data(), (size_t)cnt * nn * 8, hipMemcpyHostToDevice));
+        }
+    }
+    EpisodeSpec sp;
+    sp.num_games = G; sp.max_plies = a->max_plies; sp.add_noise = true; sp.arena = false;
+    return run_episode(e, sp, out);
+}
+
+extern "C" int az_selfplay_games(az_engine *e, int32_t *nply, int32_t *result)
+{
+    if (!e || !e->have_episode) return fail(e, AZ_ERR_STATE, "no episode has been run");
+    for (int g = 0; g < e->episode_games; g++) {
+        if (nply) nply[g] = e->h_nply[g];
+        if (result) result[g] = e->h_result[g];
+    }
+    return AZ_OK;
+}
+
+extern "C" int az_selfplay_records(az_engine *e, uint8_t *boards, uint8_t *movers, int16_t *lasts, int16_t *actions,
+                                   float *pis, int32_t *visits, int8_t *z)
+{
+    if (!e || !e->have_episode) return fail(e, AZ_ERR_STATE, "no episode has been run");
+    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    const int nn = e->nn, G = e->episode_games;
+    const size_t tot = (size_t)G * nn;
+    std::vector<u64> pl(tot * 8);
+    std::vector<short> la(tot), ac(tot);
+    std::vector<unsigned char> mv(tot);
+    std::vector<float> pi(tot * nn);
+    std::vector<unsigned short> vis(tot * nn);
+    HIPCHECK(e, hipMemcpy(pl.data(), e->rec_planes.p, pl.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHECK(e, hipMemcpy(la.data(), e->rec_last.p, la.size() * 2, hipMemcpyDeviceToHost));
+    HIPCHECK(e, hipMemcpy(ac.data(), e->rec_action.p, ac.size() * 2, hipMemcpyDeviceToHost));
+    HIPCHECK(e, hipMemcpy(mv.data(), e->rec_mover.p, mv.size(), hipMemcpyDeviceToHost));
+    HIPCHECK(e, hipMemcpy(pi.data(), e->rec_pi.p, pi.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHECK(e, hipMemcpy(vis.data(), e->rec_visits.p, vis.size() * 2, hipMemcpyDeviceToHost));
+    size_t r = 0;
+    for (int g = 0; g < G; g++) {
+        for (int m = 0; m < e->h_nply[g]; m++, r++) {
+            size_t si = (size_t)g * nn + m;
+            int mover = mv[si];
+            if (boards)
+                for (int j = 0; j < nn; j++) {
+                    bool me = (pl[si * 8 + (j >> 6)] >> (j & 63)) & 1ull, op = (pl[si * 8 + 4 + (j >> 6)] >> (j & 63)) & 1ull;
+                    boards[r * nn + j] = (uint8_t)(me ? mover : (op ? 3 - mover : 0));
+                }
+            if (movers) movers[r] = (uint8_t)mover;
+            if (lasts) lasts[r] = la[si];
+            if (actions) actions[r] = ac[si];
+            if (pis) memcpy(pis + r * nn, pi.data() + si * nn, (size_t)nn * 4);
+            if (visits) for (int j = 0; j < nn; j++) visits[r * nn + j] = vis[si * nn + j];
+            int res = e->h_result[g];
+            if (z) z[r] = (int8_t)(res == 0 ? 99 : (res == 3 ? 0 : (mover == res ? 1 : -1)));
+        }
+    }
+    return AZ_OK;
+}
+
+extern "C" int64_t az_record_bytes(const az_engine *e) { return e ? record_bytes(e->nn) : 0; }
+
+extern "C" int az_selfplay_pack(az_engine *e, void *packed_dev)
+{
+    if (!e || !e->have_episode || !packed_dev) return fail(e, AZ_ERR_STATE, "az_selfplay_pack: no episode / null buffer");
+    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    const int nn = e->nn;
+    std::vector<int> src;
+    for (int g = 0; g < e->episode_games; g++)
+        for (int m = 0; m < e->h_nply[g]; m++) src.push_back(g * nn + m);
+    if (src.empty()) return AZ_OK;
+    int rc = upload(e, e->src_index, src.data(), src.size() * 4);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)src.size()), dim3(64), 0, e->stream, e->d, (const int *)e->src_index.p,
+                       (int64_t)src.size(), nn, record_bytes(nn), (unsigned char *)packed_dev);
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    HIPCHECK(e, hipGetLastError());
+    return AZ_OK;
+}
+
+extern "C" int az_examples_from_packed(az_engine *e, const void *packed_dev, int64_t records, int aug, float *states_dev,
+                                       float *pis_dev, float *z_dev)
+{
+    if (!e || !packed_dev || !states_dev || !pis_dev || !z_dev || records < 0) return fail(e, AZ_ERR_INVALID, "az_examples_from_packed: bad argument");
+    if (aug != AZ_AUG_NONE && aug != AZ_AUG_REFERENCE4 && aug != AZ_AUG_DIHEDRAL8) return fail(e, AZ_ERR_INVALID, "aug must be 1, 4 or 8");
+    if (records == 0) return AZ_OK;
+    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    hipLaunchKernelGGL(k_examples, dim3((unsigned)records), dim3(256), 0, e->stream, (const unsigned char *)packed_dev,
+                       records, e->n, record_bytes(e->nn), aug, states_dev, pis_dev, z_dev);
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    HIPCHECK(e, hipGetLastError());
+    return AZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-position entry points
+// ------------------------------------------------------------------------------------------------
+static void planes_from_cells(const uint8_t *cells, int nn, u64 *x, u64 *o)
+{
+    for (int q = 0; q < 4; q++) x[q] = o[q] = 0;
+    for (int j = 0; j < nn; j++) {
+        if (cells[j] == 1) x[j >> 6] |= 1ull << (j & 63);
+        else if (cells[j] == 2) o[j >> 6] |= 1ull << (j & 63);
+    }
+}
+
+extern "C" int az_net_eval(az_engine *e, int slot, int count, const uint8_t *boards, const uint8_t *players,
+                           const int16_t *lasts, float *logits, float *policy, float *value)
+{
+    if (!e || slot < 0 || slot > 1 || count < 0 || !boards || !players || !lasts) return fail(e, AZ_ERR_INVALID, "az_net_eval: bad argument");
+    if (!e->net[slot].loaded) return fail(e, AZ_ERR_NO_WEIGHTS, "weights slot %d not loaded", slot);
+    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    const int nn = e->nn, B = e->d.B;
+    DevBuf dpol, dval;
+    int rc = dev_alloc(e, dpol, (size_t)B * nn * 4);
+    if (!rc) rc = dev_alloc(e, dval, (size_t)B * 4);
+    for (int c0 = 0; !rc && c0 < count; c0 += B) {
+        const int cnt = std::min(B, count - c0);
+        std::vector<u64> lf((size_t)B * 8, 0);
+        std::vector<int> kind(B, LEAF_NONE), st(B, SLOT_IDLE), nets(B, slot), ll(B, -1);
+        for (int i = 0; i < cnt; i++) {
+            u64 x[4], o[4];
+            planes_from_cells(boards + (size_t)(c0 + i) * nn, nn, x, o);
+            const bool xm = players[c0 + i] == 1;
+            for (int q = 0; q < 4; q++) { lf[(size_t)i * 8 + q] = xm ? x[q] : o[q]; lf[(size_t)i * 8 + 4 + q] = xm ? o[q] : x[q]; }
+            kind[i] = LEAF_ROOT; st[i] = SLOT_ACTIVE; ll[i] = lasts[c0 + i];
+        }
+        hipError_t hr = hipMemcpy(e->leaf.p, lf.data(), lf.size() * 8, hipMemcpyHostToDevice);
+        if (hr == hipSuccess) hr = hipMemcpy(e->leaf_kind.p, kind.data(), (size_t)B * 4, hipMemcpyHostToDevice);
+        if (hr == hipSuccess) hr = hipMemcpy(e->s_status.p, st.data(), (size_t)B * 4, hipMemcpyHostToDevice);
+        if (hr == hipSuccess) hr = hipMemcpy(e->s_net.p, nets.data(), (size_t)B * 4, hipMemcpyHostToDevice);
+        if (hr == hipSuccess) hr = hipMemcpy(e->leaf_last.p, ll.data(), (size_t)B * 4, hipMemcpyHostToDevice);
+        if (hr != hipSuccess) { rc = fail(e, AZ_ERR_HIP, "az_net_eval upload: %s", hipGetErrorString(hr)); break; }
+        DISPATCH_N(e, launch_net, e, slot);
+        DISPATCH_N(e, launch_eval_tail, e, cnt, (float *)dpol.p, (float *)dval.p);
+        hr = hipStreamSynchronize(e->stream);
+        if (hr == hipSuccess) hr = hipGetLastError();
+        if (hr == hipSuccess && logits)
+            hr = hipMemcpy2D(logits + (size_t)c0 * nn, (size_t)nn * 4, e->logits.p, (size_t)e->RW * 4, (size_t)nn * 4, cnt, hipMemcpyDeviceToHost);
+        if (hr == hipSuccess && policy) hr = hipMemcpy(policy + (size_t)c0 * nn, dpol.p, (size_t)cnt * nn * 4, hipMemcpyDeviceToHost);
+        if (hr == hipSuccess && value) hr = hipMemcpy(value + c0, dval.p, (size_t)cnt * 4, hipMemcpyDeviceToHost);
+        if (hr != hipSuccess) { rc = fail(e, AZ_ERR_HIP, "az_net_eval: %s", hipGetErrorString(hr)); break; }
+    }
+    // leave the slots idle
+    (void)hipMemset(e->s_status.p, 0, e->s_status.bytes);
+    (void)hipMemset(e->leaf_kind.p, 0, e->leaf_kind.bytes);
+    dev_free(dpol);
+    dev_free(dval);
+    return rc;
+}
+
+extern "C" int az_search(az_engine *e, int slot, const uint8_t *board, int player, int last, double temperature,
+                         const double *noise, double u, float *pi, int32_t *action, int32_t *visits, double *W,
+                         float *prior)
+{
+    if (!e || !board || (player != 1 && player != 2) || slot < 0 || slot > 1) return fail(e, AZ_ERR_INVALID, "az_search: bad argument");
+    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    const int nn = e->nn;
+    int stones = 0;
+    for (int j = 0; j < nn; j++) {
+        if (board[j] > 2) return fail(e, AZ_ERR_INVALID, "az_search: cell value %d", board[j]);
+        stones += board[j] != 0;
+    }
+    if (stones >= nn) return fail(e, AZ_ERR_INVALID, "az_search: no legal action");
+    if (last >= nn || (last >= 0 && board[last] == 0)) return fail(e, AZ_ERR_INVALID, "az_search: bad last action");
+    int rc = ensure_episode_buffers(e, 1, true);
+    if (rc) return rc;
+    std::vector<double> T(nn + 1, temperature);
+    if ((rc = upload_T(e, T.data(), false))) return rc;
+    // tape: the single ply `stones`
+    std::vector<double> hn((size_t)e->tape_len, 0.0), hu(nn, u);
+    int off = 0;
+    for (int m = 0; m < stones; m++) off += nn - m;
+    if (noise) memcpy(hn.data() + off, noise, (size_t)(nn - stones) * 8);
+    HIPCHECK(e, hipMemcpy(e->noise.p, hn.data(), hn.size() * 8, hipMemcpyHostToDevice));
+    HIPCHECK(e, hipMemcpy(e->u.p, hu.data(), hu.size() * 8, hipMemcpyHostToDevice));
+    u64 bd[8];
+    planes_from_cells(board, nn, bd, bd + 4);
+    HIPCHECK(e, hipMemsetAsync(e->s_status.p, 0, e->s_status.bytes, e->stream));
+    HIPCHECK(e, hipMemcpyAsync(e->board.p, bd, sizeof bd, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_set_position, dim3(1), dim3(64), 0, e->stream, e->d, 0, 0, player, last, stones);
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    EpisodeSpec sp;
+    sp.num_games = 1; sp.max_plies = 0; sp.add_noise = noise != nullptr; sp.arena = false; sp.preset = true; sp.profile = false;
+    // the arena flag only selects the net through s_player; a search with the baseline net uses slot 1 weights as slot 0
+    PackedNet saved0 = e->net[0];
+    const float *sv2w = e->d.v2w[0], *sv2b = e->d.v2b[0];
+    if (slot == 1) { e->net[0] = e->net[1]; e->d.v2w[0] = e->d.v2w[1]; e->d.v2b[0] = e->d.v2b[1]; }
+    rc = run_episode(e, sp, nullptr);
+    if (slot == 1) { e->net[0] = saved0; e->d.v2w[0] = sv2w; e->d.v2b[0] = sv2b; }
+    if (rc) return rc;
+    // outputs: record 0*nn + stones
+    const size_t ri = (size_t)stones;
+    if (pi) HIPCHECK(e, hipMemcpy(pi, (float *)e->rec_pi.p + ri * nn, (size_t)nn * 4, hipMemcpyDeviceToHost));
+    if (action) {
+        short a = -1;
+        HIPCHECK(e, hipMemcpy(&a, (short *)e->rec_action.p + ri, 2, hipMemcpyDeviceToHost));
+        *action = a;
+    }
+    if (visits || W || prior) {
+        std::vector<Edge> row(e->RW);
+        HIPCHECK(e, hipMemcpy(row.data(), e->edges.p, row.size() * sizeof(Edge), hipMemcpyDeviceToHost));
+        for (int j = 0; j < nn; j++) {
+            const bool legal = board[j] == 0;
+            if (visits) visits[j] = legal ? row[j].N : 0;
+            if (W) W[j] = legal ? row[j].W : 0.0;
+            if (prior) prior[j] = legal ? row[j].P : 0.0f;
+        }
+    }
+    e->have_episode = false;
+    return AZ_OK;
+}
+
+extern "C" int az_arena(az_engine *e, const az_arena_args *a, az_arena_result *out, int32_t *results, int16_t *actions,
+                        int32_t *nply)
+{
+    if (!e || !a || a->num_games < 1) return fail(e, AZ_ERR_INVALID, "az_arena: bad argument");
+    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    const int nn = e->nn, G = a->num_games;
+    int rc = ensure_episode_buffers(e, G, false);
+    if (rc) return rc;
+    if ((rc = upload_T(e, a->temperature_table, true))) return rc;
+    std::vector<double> hu((size_t)G * nn);
+    if (a->u_tape) memcpy(hu.data(), a->u_tape, hu.size() * 8);
+    else for (int g = 0; g < G; g++) azrng::uniforms(a->seed0 + (uint64_t)g, nn, hu.data() + (size_t)g * nn);
+    HIPCHECK(e, hipMemcpy(e->u.p, hu.data(), hu.size() * 8, hipMemcpyHostToDevice));
+    EpisodeSpec sp;
+    sp.num_games = G; sp.max_plies = 0; sp.add_noise = false; sp.arena = true;
+    az_counters c;
+    if ((rc = run_episode(e, sp, &c))) return rc;
+    int w = 0, l = 0, dr = 0;
+    for (int g = 0; g < G; g++) {
+        int r = e->h_result[g];
+        w += r == AZ_RES_X; l += r == AZ_RES_O; dr += r == AZ_RES_DRAW;   // candidate = X, baseline = O (evaluator.py:64)
+        if (results) results[g] = r;
+        if (nply) nply[g] = e->h_nply[g];
+    }
+    if (actions) {
+        std::vector<short> ac((size_t)G * nn);
+        HIPCHECK(e, hipMemcpy(ac.data(), e->rec_action.p, ac.size() * 2, hipMemcpyDeviceToHost));
+        for (int g = 0; g < G; g++)
+            for (int m = 0; m < nn; m++) actions[(size_t)g * nn + m] = m < e->h_nply[g] ? ac[(size_t)g * nn + m] : (int16_t)-1;
+    }
+    if (out) {
+        out->wins = w; out->losses = l; out->draws = dr; out->total = w + l + dr;
+        out->win_rate = out->total ? (w + 0.5 * dr) / out->total : 0.0;     // evaluator.py:106-109
+    }
+    return AZ_OK;
+}
+
+extern "C" int az_get_counters(const az_engine *e, az_counters *out)
+{
+    if (!e || !out) return AZ_ERR_INVALID;
+    *out = e->last;
+    return AZ_OK;
+}

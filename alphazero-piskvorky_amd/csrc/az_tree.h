@@ -1,0 +1,530 @@
+// az_tree.h -- per-wavefront MCTS kernels (select / expand / backup / move) over an array tree in HBM.
+//
+// One 64-lane wavefront owns one game slot.  A node that has been expanded owns one ROW of
+// RW = roundup(n*n, 64) edge records (16 B each: W f64, P f32, N u16, child-row u16), indexed by
+// board cell, so a level of the descent is CPL = RW/64 coalesced 16-byte loads per lane and the
+// reference's "first maximal child in row-major order" (mcts.py:71) is a (max score, min cell)
+// wave reduction.  Boards are two bit-planes of 4 x u64.  Reference semantics: mcts.py:25-183,
+// games.py:35-166, self_play.py:48-73, evaluator.py:64-90 (cited inline).
+#pragma once
+#include "az_device.h"
+
+enum { LEAF_NONE = 0, LEAF_EXPAND = 1, LEAF_TERM_LOSS = 2, LEAF_TERM_DRAW = 3, LEAF_ROOT = 4 };
+enum { SLOT_IDLE = 0, SLOT_ACTIVE = 1, SLOT_FINISHED = 2 };
+
+struct __attribute__((aligned(16))) Edge {
+    double W;              // mcts.py:38 total value (float64 like the reference)
+    float P;               // mcts.py:63 prior (float32 value widened on use)
+    unsigned short N;      // mcts.py:37 visit count
+    unsigned short child;  // row of the expanded child node, 0 = not expanded (row 0 is the root)
+};
+
+struct DevState {
+    int B, R, S, k, max_plies, add_noise, arena, total_games;
+    double c_puct, w_noise;
+    float one_minus_w;
+    // --- slots (current real game per slot) ---
+    u64 *board;            // [B][8] absolute bit-planes: words 0-3 X, 4-7 O
+    int *s_game, *s_ply, *s_player, *s_last, *s_status, *s_net;
+    // --- search state per slot ---
+    Edge *edges;           // [B][R][RW]
+    int *rows_used;        // [B]
+    unsigned *path;        // [B][PATH] (row << 16 | cell)
+    int *depth;            // [B]
+    int *leaf_kind;        // [B]
+    u64 *leaf;             // [B][8] mover-relative planes of the pending leaf: words 0-3 side to move, 4-7 opponent
+    int *leaf_last;        // [B]
+    // --- evaluator outputs ---
+    float *logits;         // [B][RW]
+    float *vhid;           // [B][64]
+    const float *v2w[2];   // value_fc2.weight per net slot
+    const float *v2b[2];
+    // --- RNG tapes per game (numpy legacy stream, see az_rng.cpp) ---
+    const double *noise;   // [G][noise_stride]
+    long long noise_stride;
+    const double *u;       // [G][nn]
+    const int *noise_off;  // [nn+1] offset of ply m inside a game's noise tape
+    // --- tables ---
+    const double *T_table; // temperature by ply (self-play) or step (arena)
+    const float *log_table;   // float32 log(N + 1e-8), N = 0..S
+    const double *sqrt_table; // sqrt(N + 1e-8), N = 0..S+1
+    // --- records per game: index game*nn + ply ---
+    u64 *rec_planes;       // [G*nn][8] mover-relative planes before the move
+    short *rec_last, *rec_action;
+    unsigned char *rec_mover;
+    float *rec_pi;         // [G*nn][nn]
+    unsigned short *rec_visits; // [G*nn][nn]
+    int *g_nply, *g_result;
+    // --- bookkeeping ---
+    unsigned long long *cnt;   // [B][4] expansions, simulations, terminal hits, depth sum
+    int *next_game;        // device counter
+    int *active;           // number of active slots after refill
+};
+
+template <int N>
+struct TreeGeo {
+    static constexpr int n = N, nn = N * N, RW = ((nn + 63) / 64) * 64, CPL = RW / 64, PATH = nn + 1;
+};
+
+__device__ __forceinline__ void wave_mem_sync()
+{
+    // orders this wave's global/LDS writes before its later reads (cross-lane hand-off inside one wave)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+
+// controller.py:49 softmax over all n^2 logits (no legality mask) in the canonical wave order, and the
+// value tail value_fc2 + tanh (net.py:70) as one k-ordered fma chain.  P[i] is the prior of cell lane+64*i.
+template <int N>
+__device__ __forceinline__ void eval_tail(const DevState &d, int b, int lane, float (&P)[TreeGeo<N>::CPL], float &v)
+{
+    typedef TreeGeo<N> G;
+    const float *lg = d.logits + (size_t)b * G::RW;
+    float x[G::CPL];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < G::CPL; i++) {
+        int j = lane + 64 * i;
+        x[i] = j < G::nn ? lg[j] : -INFINITY;
+        mx = fmaxf(mx, x[i]);
+    }
+    mx = wave_max_f(mx);
+    float part = 0.0f;
+#pragma unroll
+    for (int i = 0; i < G::CPL; i++) {
+        int j = lane + 64 * i;
+        P[i] = 0.0f;
+        if (j < G::nn) {
+            P[i] = az_expf(x[i] - mx);
+            part = part + P[i];
+        }
+    }
+    float s = wave_sum_butterfly(part);
+#pragma unroll
+    for (int i = 0; i < G::CPL; i++) P[i] = P[i] / s;
+    const float *h = d.vhid + (size_t)b * 64;
+    const float *w2 = d.v2w[d.s_net[b]];
+    float acc = 0.0f;
+    for (int i = 0; i < 64; i++) acc = __builtin_fmaf(h[i], w2[i], acc);
+    v = az_tanhf(acc + d.v2b[d.s_net[b]][0]);
+}
+
+// az_net_eval: softmax policy + value for boards staged as pending leaves (controller.py:39-53)
+template <int N>
+__global__ __launch_bounds__(256) void k_eval_tail(DevState d, int count, float *policy, float *value)
+{
+    typedef TreeGeo<N> G;
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= count) return;
+    float P[G::CPL], v;
+    eval_tail<N>(d, b, lane, P, v);
+#pragma unroll
+    for (int i = 0; i < G::CPL; i++) {
+        int j = lane + 64 * i;
+        if (j < G::nn) policy[(size_t)b * G::nn + j] = P[i];
+    }
+    if (lane == 0) value[b] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_begin: the root of every active slot becomes the pending evaluation (mcts.py:106-109)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_begin(DevState d)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= d.B) return;
+    if (d.s_status[b] != SLOT_ACTIVE) { d.leaf_kind[b] = LEAF_NONE; return; }
+    int pl = d.s_player[b];
+    const u64 *bd = d.board + (size_t)b * 8;
+    u64 *lf = d.leaf + (size_t)b * 8;
+    for (int i = 0; i < 4; i++) {
+        lf[i] = pl == 1 ? bd[i] : bd[4 + i];
+        lf[4 + i] = pl == 1 ? bd[4 + i] : bd[i];
+    }
+    d.leaf_last[b] = d.s_last[b];
+    d.leaf_kind[b] = LEAF_ROOT;
+    d.depth[b] = 0;
+    d.s_net[b] = d.arena ? (pl == 1 ? 0 : 1) : 0;   // evaluator.py:73-79: each side searches with its own net
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_step: consume the evaluation of the pending leaf (expand + backup), then select the next leaf.
+// ------------------------------------------------------------------------------------------------
+template <int N, bool SYNTH>
+__global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_select)
+{
+    typedef TreeGeo<N> G;
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= d.B) return;
+    if (d.s_status[b] != SLOT_ACTIVE) return;
+    const int kind = d.leaf_kind[b];
+    Edge *rows = d.edges + (size_t)b * d.R * G::RW;
+    unsigned *path = d.path + (size_t)b * G::PATH;
+
+    // ---------------- stage 1: evaluation -> expand -> backup ----------------
+    if (kind != LEAF_NONE) {
+        float v = 0.0f;
+        if (kind == LEAF_ROOT || kind == LEAF_EXPAND) {
+            Plane me = pl_load(d.leaf + (size_t)b * 8), opp = pl_load(d.leaf + (size_t)b * 8 + 4);
+            float P[G::CPL];
+            if (SYNTH) {
+                // build-owned deterministic evaluator (test hook behind the policy_value_fn seam, mcts.py:87-93)
+                int last = d.leaf_last[b];
+                unsigned hx = 0;
+#pragma unroll
+                for (int i = 0; i < G::CPL; i++) {
+                    int j = lane + 64 * i;
+                    if (j < G::nn) {
+                        unsigned code = pl_get(me, j) ? 1u : (pl_get(opp, j) ? 2u : 0u);
+                        hx ^= az_fmix32((unsigned)j * 3u + code + 0x9E3779B9u);
+                    }
+                }
+                unsigned hs = wave_xor_u(hx);
+                hs ^= az_fmix32(0x51ED270Bu + (unsigned)(last + 1));
+#pragma unroll
+                for (int i = 0; i < G::CPL; i++) {
+                    int j = lane + 64 * i;
+                    unsigned r = az_fmix32(hs + (unsigned)(j + 1) * 0x9E3779B1u);
+                    P[i] = (float)(((r >> 8) & 0xFFFFu) + 1u) * 0x1p-23f;
+                }
+                int vv = (int)(az_fmix32(hs ^ 0x7F4A7C15u) & 0x1FFu);
+                v = (float)(vv - 256) / 256.0f;
+            } else {
+                eval_tail<N>(d, b, lane, P, v);
+            }
+            if (kind == LEAF_ROOT && d.add_noise) {
+                // mcts.py:113-116; float32 multiply, float64 add, float32 store
+                Plane occ;
+#pragma unroll
+                for (int q = 0; q < 4; q++) occ.w[q] = me.w[q] | opp.w[q];
+                int g = d.s_game[b];
+                const double *nz = d.noise + (size_t)g * d.noise_stride + d.noise_off[d.s_ply[b]];
+#pragma unroll
+                for (int i = 0; i < G::CPL; i++) {
+                    int j = lane + 64 * i;
+                    if (j < G::nn && !pl_get(occ, j)) {
+                        int rank = j - pl_rank(occ, j);
+                        float scaled = d.one_minus_w * P[i];
+                        P[i] = (float)((double)scaled + d.w_noise * nz[rank]);
+                    }
+                }
+            }
+            // mcts.py:50-64 expand: one edge per cell (occupied cells are never selected)
+            int row = kind == LEAF_ROOT ? 0 : d.rows_used[b];
+#pragma unroll
+            for (int i = 0; i < G::CPL; i++) {
+                int j = lane + 64 * i;
+                Edge e;
+                e.W = 0.0; e.P = P[i]; e.N = 0; e.child = 0;
+                rows[(size_t)row * G::RW + j] = e;
+            }
+            if (lane == 0) {
+                d.rows_used[b] = row + 1;
+                if (kind == LEAF_EXPAND) {
+                    unsigned pe = path[d.depth[b] - 1];
+                    rows[(size_t)(pe >> 16) * G::RW + (pe & 0xFFFFu)].child = (unsigned short)row;
+                }
+            }
+        }
+        if (kind != LEAF_ROOT) {
+            // mcts.py:132-134,141,76-82: value w.r.t. the side to move at the leaf, backed up with alternating sign
+            double value = kind == LEAF_EXPAND ? (double)v : (kind == LEAF_TERM_LOSS ? -1.0 : 0.0);
+            int depth = d.depth[b];
+            for (int dd = lane; dd < depth; dd += 64) {
+                unsigned pe = path[dd];
+                Edge *e = rows + (size_t)(pe >> 16) * G::RW + (pe & 0xFFFFu);
+                double val = ((depth - 1 - dd) & 1) ? value : -value;
+                e->N = (unsigned short)(e->N + 1);
+                e->W = e->W + val;
+            }
+            if (lane == 0) {
+                unsigned long long *c = d.cnt + (size_t)b * 4;
+                c[0] += kind == LEAF_EXPAND ? 1ull : 0ull;
+                c[1] += 1ull;
+                c[2] += kind == LEAF_EXPAND ? 0ull : 1ull;
+                c[3] += (unsigned long long)depth;
+            }
+        }
+        wave_mem_sync();
+    }
+
+    // ---------------- stage 2: selection (mcts.py:124-129) ----------------
+    if (!do_select) {
+        if (lane == 0) d.leaf_kind[b] = LEAF_NONE;
+        return;
+    }
+    const int pl = d.s_player[b];
+    Plane me = pl_load(d.board + (size_t)b * 8 + (pl == 1 ? 0 : 4));
+    Plane opp = pl_load(d.board + (size_t)b * 8 + (pl == 1 ? 4 : 0));
+    int row = 0, npar = rootN, depth = 0, last = d.s_last[b], out_kind = LEAF_NONE;
+    for (;;) {
+        Plane occ;
+#pragma unroll
+        for (int q = 0; q < 4; q++) occ.w[q] = me.w[q] | opp.w[q];
+        const double sq = d.sqrt_table[npar];                 // np.sqrt(self.N + 1e-8), mcts.py:73
+        double best = 0.0;
+        int bi = -1;
+#pragma unroll
+        for (int i = 0; i < G::CPL; i++) {
+            int j = lane + 64 * i;
+            if (j < G::nn && !pl_get(occ, j)) {
+                Edge e = rows[(size_t)row * G::RW + j];
+                double Q = e.N ? e.W / (double)e.N : 0.0;     // mcts.py:80 Q = W/N (0.0 while unvisited)
+                double sc = Q + ((d.c_puct * (double)e.P) * sq) / (double)(1 + (int)e.N);
+                if (bi < 0 || sc > best) { best = sc; bi = j; }
+            }
+        }
+        wave_argmax(best, bi);
+        const int a = __builtin_amdgcn_readfirstlane(bi);
+        if (a < 0) { out_kind = LEAF_NONE; break; }            // unreachable for a non-terminal root; never index with -1
+        Edge ea = rows[(size_t)row * G::RW + a];
+        if (lane == 0) path[depth] = ((unsigned)row << 16) | (unsigned)a;
+        depth++;
+        pl_set(me, a);                                        // games.py:79-81 place, flip player, remember action
+        Plane t = me; me = opp; opp = t;
+        last = a;
+        if (wins_through(opp, a, N, d.k)) { out_kind = LEAF_TERM_LOSS; break; }  // the side to move has lost
+        if (pl_count(me) + pl_count(opp) == G::nn) { out_kind = LEAF_TERM_DRAW; break; }
+        int child = __builtin_amdgcn_readfirstlane((int)ea.child);
+        if (child == 0) { out_kind = LEAF_EXPAND; break; }    // mcts.py:127 node.is_leaf()
+        npar = __builtin_amdgcn_readfirstlane((int)ea.N);
+        row = child;
+    }
+    if (lane == 0) {
+        pl_store(d.leaf + (size_t)b * 8, me);
+        pl_store(d.leaf + (size_t)b * 8 + 4, opp);
+        d.leaf_last[b] = last;
+        d.leaf_kind[b] = out_kind;
+        d.depth[b] = depth;
+    }
+}
+
+// numpy pairwise sum of a contiguous float64 block (n <= 128), see oracle for the derivation
+__device__ inline double pw_block(const double *a, int n)
+{
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_move: visit counts -> pi -> sampled action (mcts.py:144-177), record (self_play.py:63),
+//         apply (games.py:64-82), terminal check (games.py:133-166).
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void k_move(DevState d)
+{
+    typedef TreeGeo<N> G;
+    __shared__ double ebuf_all[4][G::RW];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wv;
+    if (b >= d.B) return;
+    if (d.s_status[b] != SLOT_ACTIVE) return;
+    double *ebuf = ebuf_all[wv];
+    const int g = d.s_game[b], ply = d.s_ply[b], pl = d.s_player[b];
+    Plane X = pl_load(d.board + (size_t)b * 8), O = pl_load(d.board + (size_t)b * 8 + 4);
+    Plane occ;
+#pragma unroll
+    for (int q = 0; q < 4; q++) occ.w[q] = X.w[q] | O.w[q];
+    const int A = G::nn - pl_count(occ);
+    const Edge *root = d.edges + (size_t)b * d.R * G::RW;
+    const double T = d.T_table[d.arena ? ((ply + 1) >> 1) : ply];   // evaluator.py:71-90 step quirk
+    const double u = d.u[(size_t)g * G::nn + ply];
+
+    int Nj[G::CPL], rank[G::CPL];
+    bool legal[G::CPL];
+    double e[G::CPL];
+#pragma unroll
+    for (int i = 0; i < G::CPL; i++) {
+        int j = lane + 64 * i;
+        legal[i] = j < G::nn && !pl_get(occ, j);
+        Nj[i] = legal[i] ? (int)root[j].N : 0;
+        rank[i] = legal[i] ? j - pl_rank(occ, j) : 0;
+    }
+    bool uniform = false;
+    double s = 1.0;
+    if (T <= 1e-7) {
+        // temperature clipped to the Python float 1e-7 -> float32 arithmetic, exp() is exactly 0 or 1
+        float y[G::CPL], m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < G::CPL; i++) {
+            y[i] = legal[i] ? d.log_table[Nj[i]] / 1e-7f : -INFINITY;
+            m = fmaxf(m, y[i]);
+        }
+        m = wave_max_f(m);
+        int ties = 0;
+#pragma unroll
+        for (int i = 0; i < G::CPL; i++) {
+            y[i] = legal[i] ? ((y[i] - m) == 0.0f ? 1.0f : az_expf(y[i] - m)) : 0.0f;
+            ties += y[i] == 1.0f ? 1 : 0;
+        }
+        ties = wave_sum_i(ties);
+#pragma unroll
+        for (int i = 0; i < G::CPL; i++) e[i] = (double)(y[i] / (float)ties);
+    } else {
+        double m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < G::CPL; i++) {
+            e[i] = legal[i] ? (double)d.log_table[Nj[i]] / T : -INFINITY;
+            m = e[i] > m ? e[i] : m;
+        }
+        m = wave_max_d(m);
+#pragma unroll
+        for (int i = 0; i < G::CPL; i++) {
+            e[i] = legal[i] ? az_exp(e[i] - m) : 0.0;
+            if (legal[i]) ebuf[rank[i]] = e[i];
+        }
+        wave_mem_sync();
+        if (lane == 0) {
+            int n2 = A / 2;
+            n2 -= n2 % 8;
+            s = A <= 128 ? 0.0 + pw_block(ebuf, A) : 0.0 + (pw_block(ebuf, n2) + pw_block(ebuf + n2, A - n2));
+        }
+        s = __shfl(s, 0, 64);
+        uniform = (s < 1e-8) || (s != s);
+#pragma unroll
+        for (int i = 0; i < G::CPL; i++) e[i] = uniform ? 1.0 / (double)A : e[i] / s;
+        wave_mem_sync();
+    }
+    // RandomState.choice: cdf = p.cumsum(); cdf /= cdf[-1]; searchsorted(u, side='right')
+#pragma unroll
+    for (int i = 0; i < G::CPL; i++)
+        if (legal[i]) ebuf[rank[i]] = e[i];
+    wave_mem_sync();
+    double lastc = 0.0;
+    if (lane == 0) {
+        double run = ebuf[0];
+        for (int i = 1; i < A; i++) { run = run + ebuf[i]; ebuf[i] = run; }
+        lastc = run;
+    }
+    lastc = __shfl(lastc, 0, 64);
+    wave_mem_sync();
+    int cntle = 0;
+    for (int i = lane; i < A; i += 64) cntle += (ebuf[i] / lastc <= u) ? 1 : 0;
+    int idx = wave_sum_i(cntle);
+    if (idx >= A) idx = A - 1;
+    int mycell = -1;
+#pragma unroll
+    for (int i = 0; i < G::CPL; i++)
+        if (legal[i] && rank[i] == idx) mycell = lane + 64 * i;
+    u64 bal = __ballot(mycell >= 0);
+    int src = __ffsll((long long)bal) - 1;
+    const int a = __shfl(mycell, src, 64);
+
+    // ---- record (self_play.py:63): state before the move, pi, mover ----
+    const size_t ri = (size_t)g * G::nn + ply;
+#pragma unroll
+    for (int i = 0; i < G::CPL; i++) {
+        int j = lane + 64 * i;
+        if (j < G::nn) {
+            d.rec_pi[ri * G::nn + j] = legal[i] ? (float)e[i] : 0.0f;
+            d.rec_visits[ri * G::nn + j] = (unsigned short)Nj[i];
+        }
+    }
+    // ---- apply + terminal ----
+    Plane mine = pl == 1 ? X : O;
+    pl_set(mine, a);
+    Plane occ2 = occ;
+    pl_set(occ2, a);
+    bool win = wins_through(mine, a, N, d.k);
+    bool full = pl_count(occ2) == G::nn;
+    if (lane == 0) {
+        u64 *rp = d.rec_planes + ri * 8;
+        for (int q = 0; q < 4; q++) {
+            rp[q] = pl == 1 ? X.w[q] : O.w[q];
+            rp[4 + q] = pl == 1 ? O.w[q] : X.w[q];
+        }
+        d.rec_last[ri] = (short)d.s_last[b];
+        d.rec_mover[ri] = (unsigned char)pl;
+        d.rec_action[ri] = (short)a;
+        pl_store(d.board + (size_t)b * 8 + (pl == 1 ? 0 : 4), mine);
+        d.s_player[b] = 3 - pl;
+        d.s_last[b] = a;
+        d.s_ply[b] = ply + 1;
+        int res = win ? pl : (full ? 3 : 0);
+        bool cut = d.max_plies > 0 && ply + 1 >= d.max_plies;
+        if (res != 0 || cut) {
+            d.g_result[g] = res;
+            d.g_nply[g] = ply + 1;
+            d.s_status[b] = SLOT_FINISHED;
+        }
+        d.leaf_kind[b] = LEAF_NONE;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_refill: finished/idle slots receive the next game ids in slot order (ballot + prefix sum),
+//           replacing the task queue of self_play.py:114-118,41-45.  One block of 1024 threads.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_refill(DevState d)
+{
+    __shared__ int wsum[16];
+    __shared__ int base_s, active_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { base_s = *d.next_game; active_s = 0; }
+    __syncthreads();
+    for (int c0 = 0; c0 < d.B; c0 += 1024) {
+        int b = c0 + tid;
+        bool need = b < d.B && d.s_status[b] != SLOT_ACTIVE;
+        bool act = b < d.B && d.s_status[b] == SLOT_ACTIVE;
+        u64 bal = __ballot(need);
+        int pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wv] = __popcll(bal);
+        u64 bact = __ballot(act);
+        __syncthreads();
+        int off = 0, tot = 0;
+        for (int w = 0; w < 16; w++) { off += w < wv ? wsum[w] : 0; tot += wsum[w]; }
+        int base = base_s;
+        int newact = 0;
+        if (need) {
+            int gid = base + off + pre;
+            if (gid < d.total_games) {
+                u64 *bd = d.board + (size_t)b * 8;
+                for (int q = 0; q < 8; q++) bd[q] = 0ull;
+                d.s_game[b] = gid;
+                d.s_ply[b] = 0;
+                d.s_player[b] = (d.arena && (gid & 1)) ? 2 : 1;   // evaluator.py:64-69
+                d.s_last[b] = -1;
+                d.s_status[b] = SLOT_ACTIVE;
+                d.leaf_kind[b] = LEAF_NONE;
+                newact = 1;
+            } else {
+                d.s_status[b] = SLOT_IDLE;
+                d.s_game[b] = -1;
+            }
+        }
+        u64 bnew = __ballot(newact != 0);
+        if (lane == 0) atomicAdd(&active_s, __popcll(bnew) + __popcll(bact));
+        __syncthreads();
+        if (tid == 0) base_s = min(base + tot, d.total_games);
+        __syncthreads();
+    }
+    if (tid == 0) { *d.next_game = base_s; *d.active = active_s; }
+}
+
+// custom start position for az_search: slot 0 gets the given state
+__global__ void k_set_position(DevState d, int slot, int game, int player, int last, int ply)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    d.s_game[slot] = game;
+    d.s_ply[slot] = ply;
+    d.s_player[slot] = player;
+    d.s_last[slot] = last;
+    d.s_status[slot] = SLOT_ACTIVE;
+    d.leaf_kind[slot] = LEAF_NONE;
+}

@@ -1,0 +1,172 @@
+/*
+ * az_engine.h -- C-ABI of the MI355X-native batched self-play engine.
+ *
+ * Drop-in boundary for the hot path of VojtaHavlicek/AlphaZero-Piskvorky
+ * (alphazero/mcts.py + alphazero/self_play.py + alphazero/net.py, with games.py,
+ * controller.make_policy_value_fn and evaluator.py).  The reference has no FFI of its
+ * own: its seams are Python call signatures.  Each entry point below
+ * names the reference interface it stands behind; the Python shims in
+ * alphazero-piskvorky_amd/ keep those signatures and call this library via ctypes
+ * (INTEGRATION.md shows the binding).
+ *
+ * Conventions: every call returns 0 on success or a negative az_status; nothing throws
+ * or aborts across the boundary; the caller owns all input buffers; outputs are written
+ * into caller-provided buffers; one engine per GPU; calls on one engine are serialised by
+ * the caller; engines on different GPUs are independent.  Pointers suffixed _dev are
+ * device pointers (e.g. torch tensor.data_ptr()), all others are host pointers.
+ *
+ * The library contains NO CPU implementation of the path: az_create fails with
+ * AZ_ERR_NO_DEVICE when no gfx950 device is present.
+ */
+#ifndef AZ_ENGINE_H
+#define AZ_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct az_engine az_engine;
+
+typedef enum {
+    AZ_OK = 0,
+    AZ_ERR_INVALID = -1,     /* bad argument / unsupported configuration            */
+    AZ_ERR_NO_DEVICE = -2,   /* no HIP device (the engine has no CPU fallback)      */
+    AZ_ERR_HIP = -3,         /* a HIP runtime call failed; see az_last_error        */
+    AZ_ERR_ILLEGAL_MOVE = -4,/* games.py:76-77 ValueError("Invalid move")           */
+    AZ_ERR_NO_WEIGHTS = -5,  /* net evaluator selected but slot not loaded          */
+    AZ_ERR_STATE = -6        /* call sequence error (e.g. export before self-play)  */
+} az_status;
+
+enum { AZ_EVAL_NET = 0, AZ_EVAL_SYNTHETIC = 1 };   /* synthetic = deterministic hash evaluator (test hook, mcts.py:87-93 seam) */
+enum { AZ_RES_NONE = 0, AZ_RES_X = 1, AZ_RES_O = 2, AZ_RES_DRAW = 3 }; /* constants.py:11-13 'X','O','D' */
+enum { AZ_AUG_REFERENCE4 = 4, AZ_AUG_DIHEDRAL8 = 8, AZ_AUG_NONE = 1 };
+
+/* Hyper-parameters the reference keeps in constants.py / MCTS.__init__ (mcts.py:87-97). */
+typedef struct {
+    int32_t board_size;        /* constants.py:2  BOARD_SIZE   (5, 9 or 15)                      */
+    int32_t win_length;        /* constants.py:3  WIN_LENGTH                                     */
+    int32_t num_simulations;   /* mcts.py:89      num_simulations (<= 1024)                      */
+    int32_t slots;             /* concurrent games resident on this GPU                          */
+    double c_puct;             /* mcts.py:90                                                      */
+    double dirichlet_alpha;    /* mcts.py:91 (0.3)                                                */
+    double dirichlet_weight;   /* mcts.py:92 (0.25)                                               */
+    int32_t eval_kind;         /* AZ_EVAL_NET | AZ_EVAL_SYNTHETIC                                 */
+    int32_t device;            /* HIP device ordinal                                              */
+    /* Optional tables so that the host layer can hand over the reference's own numpy values:
+       log_table[N] = float32 log(N + 1e-8) for N = 0..num_simulations (mcts.py:161);
+       NULL -> computed with libm logf.                                                          */
+    const float *log_table;
+} az_config;
+
+/* ---- lifecycle ---- */
+int az_create(const az_config *cfg, az_engine **out);
+void az_destroy(az_engine *e);
+const char *az_last_error(const az_engine *e);   /* valid until the next call on e; e may be NULL */
+
+/* ---- weights: replaces state_dict pickling into workers (self_play.py:121,127,36) ----
+ * tensors[16] in net.py:37-53 state_dict order (conv1.weight, conv1.bias, conv2.*, conv3.*,
+ * policy_conv.*, policy_fc.*, value_conv.*, value_fc1.*, value_fc2.*), fp32, torch layouts.
+ * slot 0 = self-play / candidate, slot 1 = arena baseline (evaluator.py:53-62). */
+int az_load_weights(az_engine *e, int slot, const float *const *tensors);
+
+/* ---- batched net evaluation: controller.make_policy_value_fn (controller.py:33-55) ----
+ * boards[count][n*n] absolute cells (0 empty, 1 X, 2 O), players[count] side to move,
+ * lasts[count] last action (r*n+c, -1 none).  Outputs: logits/policy [count][n*n], value[count].
+ * Any output pointer may be NULL. */
+int az_net_eval(az_engine *e, int slot, int count, const uint8_t *boards, const uint8_t *players,
+                const int16_t *lasts, float *logits, float *policy, float *value);
+
+/* ---- single-position search: MCTS.run (mcts.py:101-183) ----
+ * noise: Dirichlet sample over the legal cells in row-major order, or NULL for add_root_noise=False;
+ * u: the uniform np.random.choice draws (mcts.py:177).  temperature as float64 (np.float64 schedules).
+ * Outputs (any may be NULL): pi[n*n] float32, action, visits[n*n], W[n*n] float64, prior[n*n]. */
+int az_search(az_engine *e, int slot, const uint8_t *board, int player, int last, double temperature,
+              const double *noise, double u, float *pi, int32_t *action, int32_t *visits, double *W,
+              float *prior);
+
+/* ---- self-play episode: SelfPlayManager.generate_self_play + _worker (self_play.py:29-77,110-159) ----
+ * Plays games with ids [0, num_games); game g draws its randomness from numpy-compatible
+ * RandomState(seed0 + g) (dirichlet then one uniform per ply) unless a tape is given.
+ * temperature_table[m], m = 0..n*n : temperature_schedule(m) evaluated by the host layer
+ * (self_play.py:24-26,53); NULL -> the reference default (exp(-m/100)+0.01)/1.01 via libm.
+ * max_plies > 0 cuts every game after that many plies (fixtures / benchmarking), 0 = play to the end.
+ * Results stay resident on the device until the next az_selfplay / az_destroy. */
+typedef struct {
+    uint64_t seed0;
+    int32_t num_games;
+    int32_t max_plies;
+    const double *temperature_table;
+    /* optional explicit tapes (tests): noise_tape[g] concatenated per game with stride tape_stride doubles,
+       u_tape[g][n*n]; NULL -> generated from seed0 + g */
+    const double *noise_tape;
+    const double *u_tape;
+    int64_t tape_stride;
+} az_selfplay_args;
+
+typedef struct {
+    int64_t games, plies, records;      /* records = plies (one per position, before augmentation)      */
+    int64_t simulations;                /* MCTS simulations run (mcts.py:123)                            */
+    int64_t expansions;                 /* non-terminal leaf evaluations (mcts.py:136-138)               */
+    int64_t root_evals;                 /* root evaluations (mcts.py:109), one per ply                   */
+    int64_t terminal_hits;              /* simulations ending in a terminal leaf (mcts.py:132-134)       */
+    int64_t depth_sum;                  /* sum of selection depths (mean depth = depth_sum/simulations)  */
+    int64_t steps;                      /* lock-step evaluation batches launched                         */
+    double seconds;                     /* device wall time of the episode                               */
+    double nn_seconds;                  /* HIP-event time inside the net kernels                         */
+    double trunk_seconds;               /* ... of which the fused conv trunk (dominant kernel)           */
+    int64_t trunk_launches;
+    int64_t trunk_boards;               /* boards evaluated by the trunk kernel (all launches)           */
+} az_counters;
+
+int az_selfplay(az_engine *e, const az_selfplay_args *args, az_counters *out);
+
+/* Per-game summary of the last episode: nply[g], result[g] (AZ_RES_*). */
+int az_selfplay_games(az_engine *e, int32_t *nply, int32_t *result);
+
+/* Raw per-ply records of the last episode, game-major then ply (tests/diagnostics):
+ * boards[records][n*n] absolute cells before the move, movers, lasts, actions, pis[records][n*n],
+ * visits[records][n*n], z[records] (self_play.py:71; 99 when the game was cut by max_plies). */
+int az_selfplay_records(az_engine *e, uint8_t *boards, uint8_t *movers, int16_t *lasts, int16_t *actions,
+                        float *pis, int32_t *visits, int8_t *z);
+
+/* Packed records for the episode-end exchange (RCCL gather over xGMI):
+ * az_record_bytes() per record: mover-relative bit-planes, last move, pi float32[n*n], z.
+ * az_selfplay_pack writes records*az_record_bytes bytes to a DEVICE buffer. */
+int64_t az_record_bytes(const az_engine *e);
+int az_selfplay_pack(az_engine *e, void *packed_dev);
+
+/* Training examples: (state f32[4,n,n], pi f32[n,n], z) with the augmentation of
+ * SelfPlayManager._augment_symmetries fused into the encode (self_play.py:94-108,146-148):
+ * AZ_AUG_REFERENCE4 reproduces the reference (state rot k*90deg, pi rot 90deg once, Q16),
+ * AZ_AUG_DIHEDRAL8 is the correct 8-fold group, AZ_AUG_NONE emits each position once.
+ * Reads `records` packed records from packed_dev (this rank's or gathered ones) and writes
+ * records*aug examples to DEVICE buffers, order (record, k). */
+int az_examples_from_packed(az_engine *e, const void *packed_dev, int64_t records, int aug,
+                            float *states_dev, float *pis_dev, float *z_dev);
+
+/* ---- arena: ModelEvaluator.evaluate (evaluator.py:38-122) ----
+ * candidate = slot 0 plays X, baseline = slot 1 plays O, odd game index => O moves first;
+ * per-game RandomState(seed0 + g), one uniform per ply; temperature_table[step] =
+ * evaluator.temperature_schedule(step) (NULL -> 0.3*exp(-step/4) via libm). */
+typedef struct {
+    uint64_t seed0;
+    int32_t num_games;
+    const double *temperature_table;
+    const double *u_tape;               /* optional [num_games][n*n] */
+} az_arena_args;
+typedef struct { int32_t wins, losses, draws, total; double win_rate; } az_arena_result;
+int az_arena(az_engine *e, const az_arena_args *args, az_arena_result *out, int32_t *results, int16_t *actions,
+             int32_t *nply);
+
+/* ---- host-side numpy-compatible RNG (legacy MT19937 RandomState; mcts.py:114,177) ---- */
+int az_rng_selfplay_tape(uint64_t seed, int board_size, double alpha, int max_plies, double *noise, double *u);
+int az_rng_uniforms(uint64_t seed, int count, double *u);
+
+int az_get_counters(const az_engine *e, az_counters *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AZ_ENGINE_H */
