@@ -89,6 +89,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise AzError(f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # torch ships its own libamdhip64.so.7; load it FIRST so that this library binds to the same HIP
+        # runtime (same soname) -- two runtimes in one process cannot both own the GPU.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for the pure C-ABI user
+            pass
         L = C.CDLL(LIB_PATH)
         L.az_last_error.restype = C.c_char_p
         L.az_last_error.argtypes = [C.c_void_p]
