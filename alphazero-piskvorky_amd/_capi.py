@@ -25,7 +25,7 @@ AZ_AUG_NONE, AZ_AUG_REFERENCE4, AZ_AUG_DIHEDRAL8 = 1, 4, 8
 
 EXPORTS = [
     "az_create", "az_destroy", "az_last_error", "az_load_weights", "az_net_eval", "az_search", "az_selfplay",
-    "az_selfplay_games", "az_selfplay_records", "az_record_bytes", "az_selfplay_pack", "az_examples_from_packed",
+    "az_selfplay_begin", "az_selfplay_step", "az_selfplay_end", "az_selfplay_games", "az_selfplay_records", "az_record_bytes", "az_selfplay_pack", "az_examples_from_packed",
     "az_arena", "az_rng_selfplay_tape", "az_rng_uniforms", "az_get_counters",
 ]
 
@@ -222,6 +222,24 @@ class Engine:
         self._check(lib().az_selfplay(self.h, C.byref(args), C.byref(c)), "az_selfplay")
         self.last_records = int(c.records)
         self.last_games = int(num_games)
+        return c.as_dict()
+
+    def selfplay_begin(self, num_games, seed0=0, max_plies=0, temperature_table=None):
+        T = None if temperature_table is None else np.ascontiguousarray(temperature_table, np.float64)
+        args = az_selfplay_args(int(seed0), int(num_games), int(max_plies), _dp(T), None, None, 0)
+        self._check(lib().az_selfplay_begin(self.h, C.byref(args)), "az_selfplay_begin")
+        self.last_games = int(num_games)
+
+    def selfplay_step(self, max_steps=1):
+        active = C.c_int32(0)
+        c = az_counters()
+        self._check(lib().az_selfplay_step(self.h, int(max_steps), C.byref(active), C.byref(c)), "az_selfplay_step")
+        return int(active.value), c.as_dict()
+
+    def selfplay_end(self):
+        c = az_counters()
+        self._check(lib().az_selfplay_end(self.h, C.byref(c)), "az_selfplay_end")
+        self.last_records = int(c.records)
         return c.as_dict()
 
     def games(self):

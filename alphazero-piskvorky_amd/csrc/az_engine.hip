@@ -53,6 +53,14 @@ struct az_engine {
     std::vector<int> h_nply, h_result;
     PackedNet net[2];
     az_counters last{};
+    // running episode (az_selfplay_begin .. az_selfplay_end)
+    struct Run {
+        bool open = false;
+        int num_games = 0, max_plies = 0, active = 0;
+        bool add_noise = true, arena = false, preset = false, profile = true;
+        az_counters c{};
+        double trunk_ms = 0.0, nn_ms = 0.0;
+    } run;
     // profiling events
     std::vector<hipEvent_t> ev;
     bool profile = true;
@@ -468,39 +476,51 @@ static int host_threads()
     return t < 1 ? 1 : (t > 64 ? 64 : t);
 }
 
-static int run_episode(az_engine *e, const EpisodeSpec &sp, az_counters *out)
+static int episode_begin(az_engine *e, const EpisodeSpec &sp)
 {
     DevState &d = e->d;
-    const int S = d.S;
     const bool net = e->cfg.eval_kind == AZ_EVAL_NET;
     if (net && !e->net[0].loaded) return fail(e, AZ_ERR_NO_WEIGHTS, "weights slot 0 not loaded");
     if (net && sp.arena && !e->net[1].loaded) return fail(e, AZ_ERR_NO_WEIGHTS, "weights slot 1 (baseline) not loaded");
     d.max_plies = sp.max_plies; d.add_noise = sp.add_noise ? 1 : 0; d.arena = sp.arena ? 1 : 0;
     d.total_games = sp.num_games;
     HIPCHECK(e, hipMemsetAsync(e->cnt.p, 0, e->cnt.bytes, e->stream));
+    az_engine::Run &r = e->run;
+    r = az_engine::Run();
+    r.num_games = sp.num_games; r.max_plies = sp.max_plies; r.add_noise = sp.add_noise; r.arena = sp.arena;
+    r.preset = sp.preset; r.profile = sp.profile;
     if (!sp.preset) {
         HIPCHECK(e, hipMemsetAsync(e->s_status.p, 0, e->s_status.bytes, e->stream));
         HIPCHECK(e, hipMemsetAsync(e->next_game.p, 0, 16, e->stream));
         hipLaunchKernelGGL(k_refill, dim3(1), dim3(1024), 0, e->stream, d);
+        HIPCHECK(e, hipMemcpyAsync(&r.active, e->active.p, 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHECK(e, hipStreamSynchronize(e->stream));
+    } else {
+        r.active = 1;
     }
-    // events for the net kernels: pairs (trunk start, trunk end, fc end) per evaluation of one ply
-    const bool prof = net && sp.profile && e->profile;
+    r.open = true;
+    e->have_episode = false;
+    return AZ_OK;
+}
+
+// plays up to max_steps plies of every active slot in lock step (one "step" = MCTS.run for each active game)
+static int episode_plies(az_engine *e, int max_steps)
+{
+    DevState &d = e->d;
+    az_engine::Run &r = e->run;
+    if (!r.open) return fail(e, AZ_ERR_STATE, "no episode is open");
+    const int S = d.S;
+    const bool net = e->cfg.eval_kind == AZ_EVAL_NET;
+    const bool prof = net && r.profile && e->profile;
     const size_t need_ev = prof ? (size_t)3 * (S + 1) : 0;
     while (e->ev.size() < need_ev) {
         hipEvent_t ev;
         HIPCHECK(e, hipEventCreate(&ev));
         e->ev.push_back(ev);
     }
-    az_counters c{};
-    int active = sp.preset ? 1 : 0;
-    if (!sp.preset) {
-        HIPCHECK(e, hipMemcpyAsync(&active, e->active.p, 4, hipMemcpyDeviceToHost, e->stream));
-        HIPCHECK(e, hipStreamSynchronize(e->stream));
-    }
+    const int nnets = r.arena ? 2 : 1;
     auto t0 = std::chrono::steady_clock::now();
-    double trunk_ms = 0.0, nn_ms = 0.0;
-    const int nnets = sp.arena ? 2 : 1;
-    while (active > 0) {
+    for (int step = 0; step < max_steps && r.active > 0; step++) {
         hipLaunchKernelGGL(k_begin, dim3((d.B + 255) / 256), dim3(256), 0, e->stream, d);
         for (int t = -1; t < S; t++) {
             if (net) {
@@ -510,19 +530,19 @@ static int run_episode(az_engine *e, const EpisodeSpec &sp, az_counters *out)
                 if (prof) HIPCHECK(e, hipEventRecord(e->ev[ei + 1], e->stream));
                 for (int id = 0; id < nnets; id++) DISPATCH_N(e, launch_fc_only, e, id);
                 if (prof) HIPCHECK(e, hipEventRecord(e->ev[ei + 2], e->stream));
-                c.trunk_launches += nnets;
+                r.c.trunk_launches += nnets;
             }
             // t = -1 consumes the root evaluation (root N = 0 for the first selection); t >= 0 consumes simulation t
             DISPATCH_N(e, launch_step, e, t + 1, (t + 1 < S) ? 1 : 0);
-            c.steps++;
+            r.c.steps++;
         }
         DISPATCH_N(e, launch_move, e);
-        c.trunk_boards += (int64_t)active * (S + 1);
-        if (sp.preset) {
-            active = 0;
+        r.c.plies += r.active;
+        if (r.preset) {
+            r.active = 0;
         } else {
             hipLaunchKernelGGL(k_refill, dim3(1), dim3(1024), 0, e->stream, d);
-            HIPCHECK(e, hipMemcpyAsync(&active, e->active.p, 4, hipMemcpyDeviceToHost, e->stream));
+            HIPCHECK(e, hipMemcpyAsync(&r.active, e->active.p, 4, hipMemcpyDeviceToHost, e->stream));
         }
         HIPCHECK(e, hipStreamSynchronize(e->stream));
         HIPCHECK(e, hipGetLastError());
@@ -531,43 +551,76 @@ static int run_episode(az_engine *e, const EpisodeSpec &sp, az_counters *out)
                 float a = 0.f, b = 0.f;
                 HIPCHECK(e, hipEventElapsedTime(&a, e->ev[3 * i], e->ev[3 * i + 1]));
                 HIPCHECK(e, hipEventElapsedTime(&b, e->ev[3 * i + 1], e->ev[3 * i + 2]));
-                trunk_ms += a;
-                nn_ms += a + b;
+                r.trunk_ms += a;
+                r.nn_ms += a + b;
             }
         }
     }
     auto t1 = std::chrono::steady_clock::now();
-    c.seconds = std::chrono::duration<double>(t1 - t0).count();
-    c.trunk_seconds = trunk_ms * 1e-3;
-    c.nn_seconds = nn_ms * 1e-3;
-    // gather counters
+    r.c.seconds += std::chrono::duration<double>(t1 - t0).count();
+    return AZ_OK;
+}
+
+static int read_counters(az_engine *e, az_counters &c)
+{
+    DevState &d = e->d;
     std::vector<unsigned long long> hc((size_t)d.B * 4);
     HIPCHECK(e, hipMemcpy(hc.data(), e->cnt.p, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    c.expansions = c.simulations = c.terminal_hits = c.depth_sum = 0;
     for (int b = 0; b < d.B; b++) {
         c.expansions += (int64_t)hc[(size_t)b * 4 + 0];
         c.simulations += (int64_t)hc[(size_t)b * 4 + 1];
         c.terminal_hits += (int64_t)hc[(size_t)b * 4 + 2];
         c.depth_sum += (int64_t)hc[(size_t)b * 4 + 3];
     }
-    e->h_nply.assign(sp.num_games, 0);
-    e->h_result.assign(sp.num_games, 0);
-    HIPCHECK(e, hipMemcpy(e->h_nply.data(), e->g_nply.p, (size_t)sp.num_games * 4, hipMemcpyDeviceToHost));
-    HIPCHECK(e, hipMemcpy(e->h_result.data(), e->g_result.p, (size_t)sp.num_games * 4, hipMemcpyDeviceToHost));
-    if (sp.preset) {
-        // az_search plays exactly one ply; the game itself is not finished by it
-        int ply1 = 0;
-        HIPCHECK(e, hipMemcpy(&ply1, e->s_ply.p, 4, hipMemcpyDeviceToHost));
-        e->h_nply[0] = 1;
-    }
-    c.games = sp.num_games;
-    for (int g = 0; g < sp.num_games; g++) c.plies += e->h_nply[g];
-    c.records = c.plies;
+    c.trunk_seconds = e->run.trunk_ms * 1e-3;
+    c.nn_seconds = e->run.nn_ms * 1e-3;
     c.root_evals = c.plies;
-    e->last = c;
-    e->episode_games = sp.num_games;
-    e->have_episode = true;
-    if (out) *out = c;
+    c.records = c.plies;
+    c.trunk_boards = c.expansions + c.root_evals;
+    c.games = e->run.num_games;
     return AZ_OK;
+}
+
+static int episode_end(az_engine *e, az_counters *out)
+{
+    az_engine::Run &r = e->run;
+    if (!r.open) return fail(e, AZ_ERR_STATE, "no episode is open");
+    int rc = read_counters(e, r.c);
+    if (rc) return rc;
+    e->h_nply.assign(r.num_games, 0);
+    e->h_result.assign(r.num_games, 0);
+    HIPCHECK(e, hipMemcpy(e->h_nply.data(), e->g_nply.p, (size_t)r.num_games * 4, hipMemcpyDeviceToHost));
+    HIPCHECK(e, hipMemcpy(e->h_result.data(), e->g_result.p, (size_t)r.num_games * 4, hipMemcpyDeviceToHost));
+    if (r.preset) {
+        e->h_nply[0] = 1;   // az_search plays exactly one ply; the game itself is not finished by it
+    } else {
+        // games still in flight when the caller stops early: report the plies played so far
+        std::vector<int> sg(e->d.B), sp(e->d.B), ss(e->d.B);
+        HIPCHECK(e, hipMemcpy(sg.data(), e->s_game.p, sg.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHECK(e, hipMemcpy(sp.data(), e->s_ply.p, sp.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHECK(e, hipMemcpy(ss.data(), e->s_status.p, ss.size() * 4, hipMemcpyDeviceToHost));
+        for (int b = 0; b < e->d.B; b++)
+            if (ss[b] == SLOT_ACTIVE && sg[b] >= 0 && sg[b] < r.num_games) e->h_nply[sg[b]] = sp[b];
+    }
+    int64_t plies = 0;
+    for (int g = 0; g < r.num_games; g++) plies += e->h_nply[g];
+    r.c.plies = r.c.records = r.c.root_evals = plies;
+    r.c.trunk_boards = r.c.expansions + r.c.root_evals;
+    e->last = r.c;
+    e->episode_games = r.num_games;
+    e->have_episode = true;
+    r.open = false;
+    if (out) *out = r.c;
+    return AZ_OK;
+}
+
+static int run_episode(az_engine *e, const EpisodeSpec &sp, az_counters *out)
+{
+    int rc = episode_begin(e, sp);
+    if (!rc) rc = episode_plies(e, 1 << 30);
+    if (!rc) rc = episode_end(e, out);
+    return rc;
 }
 
 static int upload_T(az_engine *e, const double *table, bool arena)
@@ -583,7 +636,7 @@ static int upload_T(az_engine *e, const double *table, bool arena)
     return AZ_OK;
 }
 
-extern "C" int az_selfplay(az_engine *e, const az_selfplay_args *a, az_counters *out)
+extern "C" int az_selfplay_begin(az_engine *e, const az_selfplay_args *a)
 {
     if (!e || !a || a->num_games < 1) return fail(e, AZ_ERR_INVALID, "az_selfplay: bad argument");
     HIPCHECK(e, hipSetDevice(e->cfg.device));
@@ -613,7 +666,37 @@ extern "C" int az_selfplay(az_engine *e, const az_selfplay_args *a, az_counters 
     }
     EpisodeSpec sp;
     sp.num_games = G; sp.max_plies = a->max_plies; sp.add_noise = true; sp.arena = false;
-    return run_episode(e, sp, out);
+    return episode_begin(e, sp);
+}
+
+extern "C" int az_selfplay_step(az_engine *e, int max_steps, int32_t *active_out, az_counters *progress)
+{
+    if (!e || max_steps < 0) return fail(e, AZ_ERR_INVALID, "az_selfplay_step: bad argument");
+    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    int rc = episode_plies(e, max_steps);
+    if (rc) return rc;
+    if (active_out) *active_out = e->run.active;
+    if (progress) {
+        az_counters c = e->run.c;
+        if ((rc = read_counters(e, c))) return rc;
+        *progress = c;
+    }
+    return AZ_OK;
+}
+
+extern "C" int az_selfplay_end(az_engine *e, az_counters *out)
+{
+    if (!e) return AZ_ERR_INVALID;
+    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    return episode_end(e, out);
+}
+
+extern "C" int az_selfplay(az_engine *e, const az_selfplay_args *a, az_counters *out)
+{
+    int rc = az_selfplay_begin(e, a);
+    if (!rc) rc = episode_plies(e, 1 << 30);
+    if (!rc) rc = episode_end(e, out);
+    return rc;
 }
 
 extern "C" int az_selfplay_games(az_engine *e, int32_t *nply, int32_t *result)

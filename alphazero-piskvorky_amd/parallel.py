@@ -1,0 +1,45 @@
+"""Multi-GPU sharding of self-play.
+
+Games never interact (self_play.py:41-73), so ranks play disjoint game ids with no data-path
+collective; the only exchange is at episode end: an all-gather of per-rank record counts, then an
+all-gather of the packed (planes, last move, pi, z) records padded to the largest count -- RCCL over
+xGMI when the process group is "nccl", gloo on CPU in the tests.  This replaces result_queue.put/get
+(self_play.py:73,140).
+"""
+import numpy as np
+import torch
+
+
+def shard_games(num_games, rank, world):
+    """Game ids of this rank: g with g % world == rank (static partition replacing the task queue, self_play.py:117-118)."""
+    return list(range(rank, num_games, world))
+
+
+def all_gather_packed(packed, count, record_bytes):
+    """packed: uint8 tensor [count*record_bytes] on this rank's device.  Returns (list of per-rank uint8 tensors, counts)."""
+    import torch.distributed as td
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return [packed[: count * record_bytes]], [int(count)]
+    world = td.get_world_size()
+    dev = packed.device
+    cnt = torch.tensor([count], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    td.all_gather(counts, cnt)
+    counts = [int(c.item()) for c in counts]
+    mx = max(max(counts), 1)
+    buf = torch.zeros(mx * record_bytes, dtype=torch.uint8, device=dev)
+    buf[: count * record_bytes] = packed[: count * record_bytes]
+    outs = [torch.empty_like(buf) for _ in range(world)]
+    td.all_gather(outs, buf)
+    return [o[: c * record_bytes] for o, c in zip(outs, counts)], counts
+
+
+def gather_packed_records(engine, device):
+    """Pack this rank's episode records on the device and exchange them.  Returns (uint8 tensor of all records
+    in rank order, per-rank counts)."""
+    count = engine.last_records
+    packed = torch.zeros(max(count, 1) * engine.record_bytes, dtype=torch.uint8, device=device)
+    if count:
+        engine.pack_into(packed.data_ptr())
+    parts, counts = all_gather_packed(packed, count, engine.record_bytes)
+    return torch.cat(parts) if len(parts) > 1 else parts[0], counts

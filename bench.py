@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Benchmark of the self-play hot path (BASELINE.json metric: MCTS node-expansions/s/GPU + self-play games/s,
+15x15 / 5-in-a-row, 400 simulations per move).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one ply of every concurrent game on the GPU: MCTS.run (mcts.py:101-183) for each of the
+`slots` games = 1 root evaluation + `sims` simulations, i.e. (sims + 1) lock-step batches of
+{tree kernel, conv-trunk kernel, FC kernel}.  Inputs (weights, RNG tapes) are resident in HBM before
+the timed region.  After the K timed steps the same episode is played to its end (timed separately)
+so that self-play games/s is a measured number, and the episode-end record exchange is timed.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+
+def net_flops(n):
+    """Algorithmic FLOPs (2*MAC) of one evaluation, SURVEY.md §8a a18: trunk (3 convs + 2 head convs) and FC tail."""
+    nn = n * n
+    trunk = 2 * nn * (36 * 32 + 288 * 64 + 576 * 128 + 128 * 6)
+    fc = 2 * (4 * nn * nn + 2 * nn * 64 + 64)
+    return trunk, fc
+
+
+def cpu_baseline(n, k, sims, sd, budget_games):
+    """The CPU oracle (a C restatement of the reference algorithm, see oracle/az_oracle.c) on the host cores:
+    one game per thread like self_play.py:29-45, first 2 plies of `budget_games` games."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    cores = min(os.cpu_count() or 1, 64)
+    o = orc.Oracle(n, k, sims)
+    net = orc.Net(n, sd)
+    plies = 2
+    games = max(cores, budget_games)
+    tapes = [orc.selfplay_tape(10_000 + g, n, maxply=plies) for g in range(games)]
+
+    def one(g):
+        return o.selfplay_game(net, tapes[g][0], tapes[g][1], maxply=plies)["counters"]
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        cs = list(ex.map(one, range(games)))
+    dt = time.perf_counter() - t0
+    exp = sum(c["expansions"] + c["root_evals"] for c in cs)
+    return {"value": exp / dt, "unit": "node-expansions/s", "cores": cores, "kind": "port",
+            "sample": f"CPU oracle (C restatement of mcts.py/net.py), first {plies} plies of {games} games, "
+                      f"{n}x{n}/{k}, {sims} sims, one game per thread, {dt:.1f}s",
+            "seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--board", type=int, default=15)
+    ap.add_argument("--win", type=int, default=5)
+    ap.add_argument("--sims", type=int, default=400)
+    ap.add_argument("--slots", type=int, default=1024, help="concurrent games per GPU")
+    ap.add_argument("--no-episode", action="store_true", help="skip playing the episode to its end")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    dist = world > 1
+    if dist:
+        import torch.distributed as td
+        torch.cuda.set_device(local)
+        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+
+    import alphazero_piskvorky_amd as az
+    from alphazero_piskvorky_amd.weights import synthetic_state_dict
+    from alphazero_piskvorky_amd import parallel
+
+    n, k, S, B = a.board, a.win, a.sims, a.slots
+    sd = synthetic_state_dict(n)
+    eng = az.Engine(n, k, S, B, device=local)
+    eng.load_weights(sd, 0)
+    # every rank plays its own shard of the episode's games: ids rank*B .. rank*B+B-1 (seed = seed0 + id)
+    eng.selfplay_begin(B, seed0=1_000_000 + rank * B)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    if a.warmup > 0:
+        eng.selfplay_step(a.warmup)
+    barrier()
+    _, c0 = eng.selfplay_step(0)
+    t0 = time.perf_counter()
+    active, c1 = eng.selfplay_step(a.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    d = {key: c1[key] - c0[key] for key in c1}
+    exp_local = d["expansions"] + (d["plies"])           # leaf expansions + root expansions (mcts.py:120,136-138)
+    sums = torch.tensor([exp_local, d["simulations"], d["plies"], d["depth_sum"], d["terminal_hits"]],
+                        dtype=torch.float64, device=dev)
+    if dist:
+        td.all_reduce(sums, op=td.ReduceOp.SUM)
+    exp_all, sims_all, plies_all, depth_all, term_all = [float(x) for x in sums.tolist()]
+
+    # ---- play the episode to its end: measured games/s, then the episode-end record exchange ----
+    episode = None
+    if not a.no_episode:
+        te0 = time.perf_counter()
+        while active > 0:
+            active, _ = eng.selfplay_step(16)
+        cend = eng.selfplay_end()
+        torch.cuda.synchronize()
+        ep_local = cend["seconds"]
+        tg0 = time.perf_counter()
+        packed, counts = parallel.gather_packed_records(eng, dev)
+        torch.cuda.synchronize()
+        tg = time.perf_counter() - tg0
+        ep = torch.tensor([ep_local, tg], dtype=torch.float64, device=dev)
+        tot = torch.tensor([cend["games"], cend["expansions"] + cend["plies"], cend["plies"]], dtype=torch.float64, device=dev)
+        if dist:
+            td.all_reduce(ep, op=td.ReduceOp.MAX)
+            td.all_reduce(tot, op=td.ReduceOp.SUM)
+        ep_s, tg_s = [float(x) for x in ep.tolist()]
+        g_all, e_all, p_all = [float(x) for x in tot.tolist()]
+        episode = {"games": int(g_all), "seconds": ep_s, "games_per_sec": g_all / ep_s,
+                   "node_expansions_per_sec": e_all / ep_s, "mean_plies_per_game": p_all / g_all,
+                   "record_gather_seconds": tg_s, "records_gathered": int(sum(counts))}
+    else:
+        eng.selfplay_end()
+
+    if rank == 0:
+        trunk_f, fc_f = net_flops(n)
+        boards = d["expansions"] + d["plies"]            # boards the trunk kernel evaluated on this rank
+        launches = max(d["trunk_launches"], 1)
+        avg_ms = d["trunk_seconds"] * 1e3 / launches
+        achieved = (boards / launches) * trunk_f / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        peak = 157.3
+        out = {
+            "metric": "mcts_node_expansions_per_sec", "value": exp_all / dt, "unit": "node-expansions/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / max(a.steps, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{n}x{n} / {k}-in-a-row self-play, {B} concurrent games per GPU, {S} sims/move "
+                                   f"(BASELINE.json configs[3] per-GPU shard), GomokuNet random-init weights, numpy-compatible RNG tapes",
+                       "board": n, "win_length": k, "sims_per_move": S, "games_per_gpu": B, "parallelism": f"games sharded x{world}"},
+            "per_gpu_node_expansions_per_sec": exp_all / dt / world,
+            "simulations_per_sec": sims_all / dt, "plies_per_sec": plies_all / dt,
+            "mean_select_depth": depth_all / max(sims_all, 1), "terminal_hit_fraction": term_all / max(sims_all, 1),
+            "self_play_games_per_sec": None if episode is None else episode["games_per_sec"],
+            "episode": episode,
+            "roofline": {"kernel": f"k_trunk<{n}> (encode+conv1+conv2+conv3+head convs, LDS-resident, v_mfma_f32_16x16x4_f32)",
+                         "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None, "avg_launch_ms": avg_ms, "boards_per_launch": boards / launches,
+                         "flops_per_board": trunk_f, "net_time_fraction": d["nn_seconds"] / max(d["seconds"], 1e-9)},
+        }
+        if not a.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(n, k, S, sd, 0)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    eng.close()
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -122,6 +122,14 @@ typedef struct {
 
 int az_selfplay(az_engine *e, const az_selfplay_args *args, az_counters *out);
 
+/* The same episode in pieces (benchmarks, pipelined callers): begin uploads tapes and fills the slots;
+ * step plays up to max_steps plies of every active game in lock step (one step = MCTS.run for each
+ * active game = 1 + num_simulations evaluation batches) and reports the number of still-active slots and,
+ * optionally, the counters so far; end finalises the per-game results. */
+int az_selfplay_begin(az_engine *e, const az_selfplay_args *args);
+int az_selfplay_step(az_engine *e, int max_steps, int32_t *active_out, az_counters *progress);
+int az_selfplay_end(az_engine *e, az_counters *out);
+
 /* Per-game summary of the last episode: nply[g], result[g] (AZ_RES_*). */
 int az_selfplay_games(az_engine *e, int32_t *nply, int32_t *result);
 
