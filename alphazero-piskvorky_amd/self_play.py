@@ -1,0 +1,79 @@
+"""SelfPlayManager seam (self_play.py:24-159): the whole episode runs in the HIP engine, one engine per GPU,
+games sharded over the ranks of torch.distributed when it is initialised, records exchanged once at episode end."""
+from collections.abc import Callable
+
+import numpy as np
+import torch
+
+from . import constants as _c
+from . import parallel
+from ._capi import AZ_AUG_REFERENCE4, Engine
+from .controller import device_index
+from .mcts import numpy_log_table
+
+
+def default_temperature_schedule(move: int) -> float:
+    norm = 1 + _c.TEMPERATURE_BASELINE
+    return (np.exp(-move / _c.TEMPERATURE_SCHEDULE_HALFTIME) + _c.TEMPERATURE_BASELINE) / norm
+
+
+class SelfPlayManager:
+    def __init__(self, controller, device, mcts_params: dict = None,
+                 temperature_schedule: Callable[[int], float] = default_temperature_schedule,
+                 concurrent_games: int = None, augmentation: int = AZ_AUG_REFERENCE4, seed: int = None):
+        self.controller = controller
+        self.device = device
+        self.mcts_params = mcts_params or {"num_simulations": 100}
+        self.temperature_schedule = temperature_schedule
+        self.concurrent_games = concurrent_games or _c.CONCURRENT_GAMES
+        self.augmentation = augmentation      # 4 = the reference's rotations (self_play.py:94-108), 8 = full dihedral group, 1 = none
+        self.seed = seed
+        self.last_counters = None
+        self._engine = None
+
+    def _eng(self, n, k, slots):
+        p = self.mcts_params
+        key = (n, k, p.get("num_simulations", 100), slots, p.get("c_puct", _c.SELF_PLAY_EXPLORATION_CONSTANT),
+               p.get("dirichlet_alpha", 0.3), p.get("dirichlet_weight", 0.25))
+        if self._engine is None or self._engine_key != key:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = Engine(n, k, key[2], slots, c_puct=key[4], dirichlet_alpha=key[5], dirichlet_weight=key[6],
+                                  device=device_index(self.device), log_table=numpy_log_table(key[2]))
+            self._engine_key = key
+        return self._engine
+
+    def generate_self_play(self, num_games: int, num_workers: int = None, flatten=False) -> list:
+        """Returns list[(state f32 (4,n,n) CPU tensor, pi f32 (n,n) ndarray, z int)] in (game, ply, k) order
+        (self_play.py:110-159; num_workers / flatten are accepted and unused like the reference's `flatten`)."""
+        import torch.distributed as td
+        n = self.controller.net.board_size
+        k = min(_c.WIN_LENGTH, n)
+        rank, world = (td.get_rank(), td.get_world_size()) if td.is_available() and td.is_initialized() else (0, 1)
+        per = (num_games + world - 1) // world
+        lo, hi = min(rank * per, num_games), min((rank + 1) * per, num_games)
+        mine = hi - lo
+        seed0 = self.seed if self.seed is not None else int(np.random.randint(0, 2 ** 31 - 1))
+        if world > 1 and self.seed is None:
+            s = torch.tensor([seed0], dtype=torch.int64, device=torch.device("cuda", device_index(self.device)))
+            td.broadcast(s, 0)
+            seed0 = int(s.item())
+        dev = torch.device("cuda", device_index(self.device))
+        eng = self._eng(n, k, max(1, min(self.concurrent_games, max(mine, 1))))
+        eng.load_weights(self.controller.net.state_dict(), 0)
+        T = np.array([float(self.temperature_schedule(m)) for m in range(n * n + 1)], dtype=np.float64)
+        if mine > 0:
+            self.last_counters = eng.selfplay(mine, seed0=seed0 + lo, temperature_table=T)
+        else:
+            eng.last_records = 0
+        packed, counts = parallel.gather_packed_records(eng, dev)
+        total = int(sum(counts))
+        aug = self.augmentation
+        states = torch.empty((total * aug, 4, n, n), dtype=torch.float32, device=dev)
+        pis = torch.empty((total * aug, n, n), dtype=torch.float32, device=dev)
+        zs = torch.empty(total * aug, dtype=torch.float32, device=dev)
+        if total:
+            eng.examples_from_packed(packed.data_ptr(), total, aug, states.data_ptr(), pis.data_ptr(), zs.data_ptr())
+        states, pis, zs = states.cpu(), pis.cpu().numpy(), zs.cpu().numpy().astype(np.int64)
+        print(f"[SelfPlayManager] Collected {len(zs)} examples from {num_games} games.")
+        return [(states[i], pis[i], int(zs[i])) for i in range(len(zs))]

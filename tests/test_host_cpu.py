@@ -1,0 +1,129 @@
+"""CPU tests of the host layer: the C-ABI library loads and exports every symbol of include/az_engine.h,
+the host RNG reproduces numpy's legacy RandomState bit for bit, the host Gomoku class follows the golden
+rules vectors, and the product refuses to run without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import alphazero_piskvorky_amd as az
+from alphazero_piskvorky_amd import _capi, games, net, self_play, evaluator, weights
+from tests.util import ROOT, SIZES, build_weights, load
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "az_engine.h")).read()
+    declared = set(re.findall(r"\b(az_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    L = ctypes.CDLL(_capi.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, f"declared in include/az_engine.h but not exported: {missing}"
+    assert set(_capi.EXPORTS) <= declared
+
+
+def test_no_cpu_fallback_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(az.AzError) as ei:
+        az.Engine(5, 4, 10, 4)
+    assert "no HIP device" in str(ei.value) or "-2" in str(ei.value)
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "alphazero-piskvorky_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("the oracle", "").replace("see oracle for", "") or f == "weights.py", \
+                    f"{f} mentions the oracle"
+
+
+@pytest.mark.parametrize("n", [5, 9, 15])
+def test_host_rng_matches_numpy_randomstate(n):
+    nn = n * n
+    for seed in (0, 7, 900, 2 ** 31 + 5):
+        noise, u = _capi.rng_selfplay_tape(seed, n)
+        rs = np.random.RandomState(seed & 0xFFFFFFFF)
+        off = 0
+        for m in range(nn):
+            d = rs.dirichlet([0.3] * (nn - m))
+            assert np.array_equal(d, noise[off:off + nn - m])
+            assert rs.random_sample() == u[m]
+            off += nn - m
+
+
+def test_host_rng_other_alphas_and_uniforms():
+    for alpha in (1.0, 2.5, 0.03):
+        noise, u = _capi.rng_selfplay_tape(42, 5, alpha=alpha, max_plies=3)
+        rs = np.random.RandomState(42)
+        off = 0
+        for m in range(3):
+            assert np.array_equal(rs.dirichlet([alpha] * (25 - m)), noise[off:off + 25 - m])
+            assert rs.random_sample() == u[m]
+            off += 25 - m
+    assert np.array_equal(_capi.rng_uniforms(5, 1000), np.random.RandomState(5).random_sample(1000))
+
+
+@pytest.mark.parametrize("n,k", SIZES)
+def test_host_gomoku_follows_golden_rules(n, k):
+    z = load(f"rules_{n}x{k}.npz")
+    code = {None: 0, "X": 1, "O": 2, "D": 3}
+    for g in range(min(len(z["nply"]), 25)):
+        s = games.Gomoku(n, k)
+        for m in range(int(z["nply"][g])):
+            assert not s.is_terminal()
+            a = int(z["actions"][g, m])
+            s = s.apply_action((a // n, a % n))
+        assert s.is_terminal() and code[s.get_game_result()] == int(z["result"][g])
+    for i in range(min(len(z["enc_game"]), 40)):
+        g, p = int(z["enc_game"][i]), int(z["enc_ply"][i])
+        s = games.Gomoku(n, k)
+        for m in range(p):
+            a = int(z["actions"][g, m]); s = s.apply_action((a // n, a % n))
+        assert np.array_equal(s.encode("cpu").numpy().astype(np.uint8), z["enc_planes"][i])
+        legal = np.zeros(n * n, np.uint8)
+        for r, c in s.get_legal_actions():
+            legal[r * n + c] = 1
+        assert np.array_equal(legal, z["legal_masks"][i])
+    s = games.Gomoku(n, k).apply_action((0, 0))
+    with pytest.raises(ValueError):
+        s.apply_action((0, 0))
+
+
+def test_synthetic_weights_equal_fixture_generator():
+    for n in (5, 15):
+        a, b = weights.synthetic_state_dict(n), build_weights(n)
+        assert list(a) == list(b) == _capi.STATE_DICT_ORDER
+        assert all(np.array_equal(a[k], b[k]) for k in a)
+
+
+def test_torch_net_has_reference_state_dict_abi_and_numbers():
+    z = load("net_5.npz")
+    m = net.GomokuNet(board_size=5)
+    assert list(m.state_dict().keys()) == _capi.STATE_DICT_ORDER
+    m.load_state_dict({k[len("ckpt_saved__"):]: torch.tensor(z[k]) for k in z.files if k.startswith("ckpt_saved__")})
+    m.eval()
+    xs = []
+    for i in range(len(z["players"])):
+        s = games.Gomoku(5, 4)
+        s.cells = z["boards"][i].copy(); s.current_player = "X" if z["players"][i] == 1 else "O"
+        la = int(z["lasts"][i]); s.last_action = None if la < 0 else (la // 5, la % 5)
+        xs.append(s.encode("cpu"))
+    with torch.no_grad():
+        logits, v = m(torch.stack(xs))
+    np.testing.assert_allclose(logits.numpy(), z["ckpt_saved_logits"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(v.numpy().reshape(-1), z["ckpt_saved_value"], rtol=0, atol=1e-6)
+
+
+def test_temperature_schedules_match_reference_values():
+    # 1.0 at m=0, 0.906 at 10, 0.374 at 100; a23: 0.3*exp(-step/4)
+    assert self_play.default_temperature_schedule(0) == 1.0
+    assert abs(self_play.default_temperature_schedule(10) - 0.9058) < 1e-3
+    assert abs(self_play.default_temperature_schedule(100) - 0.3741) < 1e-3
+    z = load("arena_5x4.npz")
+    t = z["temps"][0]
+    assert t[0] == evaluator.temperature_schedule(0) and t[1] == evaluator.temperature_schedule(1) and t[2] == t[1]

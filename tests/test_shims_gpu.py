@@ -1,0 +1,108 @@
+"""GPU tests of the drop-in Python seams: same call signatures and contracts as the reference."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.util import load, weights_from_fixture
+
+from alphazero_piskvorky_amd import constants, games, net
+from alphazero_piskvorky_amd.controller import NeuralNetworkController, make_policy_value_fn
+from alphazero_piskvorky_amd.evaluator import ModelEvaluator
+from alphazero_piskvorky_amd.mcts import MCTS
+from alphazero_piskvorky_amd.self_play import SelfPlayManager, default_temperature_schedule
+
+
+def _controller(tag, n=5):
+    m = net.GomokuNet(board_size=n)
+    m.load_state_dict({k: torch.tensor(v) for k, v in weights_from_fixture(n, tag).items()})
+    m.eval()
+    return NeuralNetworkController(m, device="cuda:0")
+
+
+def test_make_policy_value_fn_matches_reference_numbers():
+    z = load("net_5.npz")
+    pvf = make_policy_value_fn(_controller("ckpt_saved"))
+    for i in range(len(z["players"])):
+        s = games.Gomoku(5, 4)
+        s.cells = z["boards"][i].copy(); s.current_player = "X" if z["players"][i] == 1 else "O"
+        la = int(z["lasts"][i]); s.last_action = None if la < 0 else (la // 5, la % 5)
+        P, v = pvf(s)
+        assert P.shape == (5, 5) and P.dtype == np.float32 and isinstance(v, float)
+        np.testing.assert_allclose(P.reshape(-1), z["ckpt_saved_P"][i], rtol=0, atol=1e-6)
+        assert abs(v - float(z["ckpt_saved_v1"][i])) <= 2e-6
+
+
+def test_mcts_run_reproduces_reference_games_under_np_random_seed():
+    """The _worker loop body (self_play.py:48-65) driven through the MCTS.run shim with np.random.seed,
+    against the reference's recorded trajectories."""
+    z = load("netgame_5x4.npz")
+    m = MCTS(make_policy_value_fn(_controller("ckpt_saved")), num_simulations=int(z["S"]), c_puct=2.0)
+    matched = 0
+    games_ = np.unique(z["game"])
+    for g in games_:
+        sel = np.where(z["game"] == g)[0]
+        np.random.seed(int(z["seed0"]) + int(g))
+        s = games.Gomoku(5, 4); mv = 0; ok = True
+        while not s.is_terminal():
+            pi, a = m.run(s, temperature=default_temperature_schedule(mv), add_root_noise=True)
+            assert pi.shape == (5, 5) and pi.dtype == np.float32 and abs(float(pi.sum()) - 1.0) < 1e-5
+            if mv < len(sel) and a[0] * 5 + a[1] == int(z["action"][sel[mv]]) and ok:
+                assert np.array_equal(m.last_visits.reshape(-1), z["N"][sel[mv]])
+                np.testing.assert_allclose(pi.reshape(-1), z["pi"][sel[mv]], rtol=0, atol=1e-6)
+            else:
+                ok = False
+            s = s.apply_action(a); mv += 1
+        matched += ok and mv == len(sel)
+    assert matched >= len(games_) - 1
+
+
+def test_generate_self_play_contract():
+    ctrl = _controller("ckpt_saved")
+    mgr = SelfPlayManager(ctrl, "cuda:0", mcts_params={"num_simulations": 40, "c_puct": 2.0}, concurrent_games=8, seed=77)
+    data = mgr.generate_self_play(num_games=12, num_workers=3)
+    c = mgr.last_counters
+    assert len(data) == 4 * c["plies"]                                   # 4 "symmetries" per position (self_play.py:146-148)
+    s, p, zval = data[0]
+    assert isinstance(s, torch.Tensor) and s.dtype == torch.float32 and tuple(s.shape) == (4, 5, 5) and s.is_contiguous() and s.device.type == "cpu"
+    assert isinstance(p, np.ndarray) and p.dtype == np.float32 and p.shape == (5, 5) and p.flags["C_CONTIGUOUS"]
+    assert isinstance(zval, int)
+    assert all(abs(float(pp.sum()) - 1.0) < 1e-5 for _, pp, _ in data[::7])
+    assert set(zz for _, _, zz in data) <= {-1, 0, 1}
+    assert float(data[0][0].sum()) == 0.0                                # first position of game 0: empty board
+    # k = 0 record equals the engine's raw record; k = 1..3 follow the reference's rotation rule
+    raw = mgr._engine.records()
+    for r in (0, 5, c["plies"] - 1):
+        assert np.array_equal(data[4 * r + 2][0].numpy(), np.rot90(data[4 * r][0].numpy(), 2, (1, 2)))
+        for kk in range(4):
+            assert np.array_equal(data[4 * r + kk][1], np.rot90(raw["pis"][r].reshape(5, 5)))
+    # training consumes the examples (controller.py:133-178 shape guard + AdamW step)
+    out = ctrl.train(data[:256], epochs=1)
+    assert np.isfinite(out["loss"])
+    # same seed -> same examples whatever the number of concurrent slots (per-game RNG streams)
+    ctrl2 = _controller("ckpt_saved")
+    d2 = SelfPlayManager(ctrl2, "cuda:0", mcts_params={"num_simulations": 40, "c_puct": 2.0}, concurrent_games=5, seed=77).generate_self_play(12)
+    ctrl3 = _controller("ckpt_saved")
+    d3 = SelfPlayManager(ctrl3, "cuda:0", mcts_params={"num_simulations": 40, "c_puct": 2.0}, concurrent_games=12, seed=77).generate_self_play(12)
+    assert len(d2) == len(d3) and all(np.array_equal(a[1], b[1]) and a[2] == b[2] for a, b in zip(d2, d3))
+
+
+def test_model_evaluator_matches_reference_arena():
+    z = load("arena_5x4.npz")
+    constants.NUM_EVAL_SIMULATIONS = int(z["S"])
+    ev = ModelEvaluator(game_class=games.Gomoku, print_games=False, device="cuda:0", seed=int(z["seed0"]))
+    wr, metrics = ev.evaluate(_controller("ckpt_saved"), _controller("ckpt_0802"), num_games=z["actions"].shape[0])
+    constants.NUM_EVAL_SIMULATIONS = 200
+    assert set(metrics) == {"wins", "losses", "draws", "total", "win_rate"}
+    r = ev.last_result
+    same = sum(np.array_equal(r["actions"][g][:int(r["nply"][g])], z["actions"][g][z["actions"][g] >= 0]) for g in range(metrics["total"]))
+    assert same >= metrics["total"] - 1
+    if same == metrics["total"]:
+        assert (metrics["wins"], metrics["losses"], metrics["draws"]) == (int(z["wins"]), int(z["losses"]), int(z["draws"]))
+        assert abs(wr - float(z["win_rate"])) < 1e-12
+
+
+def test_mcts_rejects_python_callables():
+    with pytest.raises(NotImplementedError):
+        MCTS(lambda s: (None, 0.0), num_simulations=10, c_puct=2.0)
