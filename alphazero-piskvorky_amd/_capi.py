@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaz_engine.so")
+LIB_PATH = os.environ.get("AZ_ENGINE_LIB") or os.path.join(_HERE, "libaz_engine.so")   # override: experiment builds
 
 STATE_DICT_ORDER = [
     "conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "conv3.weight", "conv3.bias",

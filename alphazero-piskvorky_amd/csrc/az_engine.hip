@@ -37,15 +37,16 @@ struct PackedNet {
 
 struct az_engine {
     az_config cfg{};
-    int n = 0, nn = 0, RW = 0, R = 0, PATH = 0;
+    int n = 0, nn = 0, RW = 0, R = 0, PATH = 0, num_cus = 256;
     std::string err;
     hipStream_t stream = nullptr;
     DevState d{};
     std::vector<DevBuf *> owned;
     // per-engine buffers
     DevBuf board, s_game, s_ply, s_player, s_last, s_status, s_net, edges, rows_used, path, depth, leaf_kind, leaf,
-        leaf_last, logits, vhid, pol_feat, val_feat, T_table, log_table, sqrt_table, noise_off, cnt, next_game, active;
+        leaf_last, logits, vhid, pol_feat, val_feat, T_table, log_table, sqrt_table, noise_off, cnt, next_game, active, ticket;
     // per-episode buffers
+    DevBuf dbg;
     DevBuf noise, u, rec_planes, rec_last, rec_action, rec_mover, rec_pi, rec_visits, g_nply, g_result, src_index;
     int episode_games = 0, episode_capacity = 0;
     int64_t tape_len = 0;          // doubles per game in the noise tape
@@ -146,7 +147,8 @@ static std::vector<float> pack_heads(const float *pw, const float *vw)
 static std::vector<float> pack_fc(const float *w, int nout, int kin)
 {
     // torch Linear [out][in]; tile t covers outputs 16t..16t+15; k-step s covers k = 4s..4s+3
-    const int nt = (nout + 15) / 16, ks = (kin + 3) / 4, ks4 = (ks + 3) / 4;
+    // weight groups are zero-padded to whole chunks of 16 (k_fc fetches a chunk ahead)
+    const int nt = (nout + 15) / 16, ks = (kin + 3) / 4, ks4 = (((ks + 3) / 4 + 15) / 16) * 16;
     std::vector<float> out((size_t)nt * ks4 * 64 * 4, 0.0f);
     for (int t = 0; t < nt; t++)
         for (int s = 0; s < ks; s++)
@@ -166,37 +168,36 @@ static void launch_net(az_engine *e, int net_id)
 {
     typedef NetGeo<N> G;
     const int B = e->d.B;
-    dim3 gt((B + G::G - 1) / G::G), bt(512);
-    hipLaunchKernelGGL(k_trunk<N>, gt, bt, 0, e->stream, e->d, e->net[net_id].w, net_id, (float *)e->pol_feat.p,
-                       (float *)e->val_feat.p);
-    dim3 gf((B + 15) / 16, G::NSPLIT), bf(256);
+    dim3 gt((B + G::G - 1) / G::G), bt(AZ_NW * 64);
+    hipLaunchKernelGGL(k_trunk<N>, gt, bt, 0, e->stream, e->d, e->net[net_id].w, net_id, (float *)e->pol_feat.p, (unsigned long long *)e->dbg.p);
+    dim3 gf((B + 15) / 16, G::NSPLIT), bf(G::FCW * 64);
     hipLaunchKernelGGL(k_fc<N>, gf, bf, 0, e->stream, e->d, e->net[net_id].w, net_id, (const float *)e->pol_feat.p,
-                       (const float *)e->val_feat.p);
+                       e->dbg.p ? (unsigned long long *)e->dbg.p + (size_t)e->d.B * 16 : nullptr);
 }
 template <int N>
 static void launch_trunk_only(az_engine *e, int net_id)
 {
     typedef NetGeo<N> G;
-    dim3 gt((e->d.B + G::G - 1) / G::G), bt(512);
-    hipLaunchKernelGGL(k_trunk<N>, gt, bt, 0, e->stream, e->d, e->net[net_id].w, net_id, (float *)e->pol_feat.p,
-                       (float *)e->val_feat.p);
+    dim3 gt((e->d.B + G::G - 1) / G::G), bt(AZ_NW * 64);
+    hipLaunchKernelGGL(k_trunk<N>, gt, bt, 0, e->stream, e->d, e->net[net_id].w, net_id, (float *)e->pol_feat.p, (unsigned long long *)e->dbg.p);
 }
 template <int N>
 static void launch_fc_only(az_engine *e, int net_id)
 {
     typedef NetGeo<N> G;
-    dim3 gf((e->d.B + 15) / 16, G::NSPLIT), bf(256);
+    dim3 gf((e->d.B + 15) / 16, G::NSPLIT), bf(G::FCW * 64);
     hipLaunchKernelGGL(k_fc<N>, gf, bf, 0, e->stream, e->d, e->net[net_id].w, net_id, (const float *)e->pol_feat.p,
-                       (const float *)e->val_feat.p);
+                       e->dbg.p ? (unsigned long long *)e->dbg.p + (size_t)e->d.B * 16 : nullptr);
 }
 template <int N>
 static void launch_step(az_engine *e, int rootN, int do_select)
 {
     dim3 g((e->d.B + 3) / 4), b(256);
+    const size_t lds = (size_t)(e->d.S + 2) * sizeof(double);   // sqrt table
     if (e->cfg.eval_kind == AZ_EVAL_SYNTHETIC)
-        hipLaunchKernelGGL((k_step<N, true>), g, b, 0, e->stream, e->d, rootN, do_select);
+        hipLaunchKernelGGL((k_step<N, true>), g, b, lds, e->stream, e->d, rootN, do_select);
     else
-        hipLaunchKernelGGL((k_step<N, false>), g, b, 0, e->stream, e->d, rootN, do_select);
+        hipLaunchKernelGGL((k_step<N, false>), g, b, lds, e->stream, e->d, rootN, do_select);
 }
 template <int N>
 static void launch_move(az_engine *e)
@@ -346,12 +347,16 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
     ALLOC(s_game, B * 4); ALLOC(s_ply, B * 4); ALLOC(s_player, B * 4); ALLOC(s_last, B * 4);
     ALLOC(s_status, B * 4); ALLOC(s_net, B * 4);
     ALLOC(edges, B * (size_t)e->R * e->RW * sizeof(Edge));
-    ALLOC(rows_used, B * 4); ALLOC(path, B * (size_t)e->PATH * 4); ALLOC(depth, B * 4);
+    ALLOC(rows_used, B * 4); ALLOC(depth, B * 4);
+    ALLOC(path, (B * (size_t)e->PATH + 64) * 4);   // +64: k_step's speculative path[lane] read of the last slot
     ALLOC(leaf_kind, B * 4); ALLOC(leaf, B * 8 * sizeof(u64)); ALLOC(leaf_last, B * 4);
     ALLOC(logits, B * (size_t)e->RW * 4); ALLOC(vhid, B * 64 * 4);
-    ALLOC(pol_feat, B * (size_t)4 * e->nn * 4); ALLOC(val_feat, B * (size_t)2 * e->nn * 4);
-    ALLOC(cnt, B * 4 * sizeof(unsigned long long)); ALLOC(next_game, 16); ALLOC(active, 16);
+    ALLOC(pol_feat, B * (size_t)(((6 * e->nn + 3) / 4) * 4) * 4);   // feature rows [B][FROW], zero tail stays zero
+    ALLOC(cnt, B * 4 * sizeof(unsigned long long)); ALLOC(next_game, 16); ALLOC(active, 16); ALLOC(ticket, 16);
     ALLOC(T_table, (size_t)(e->nn + 4) * sizeof(double));
+#ifdef AZ_STAMPS
+    ALLOC(dbg, (B * 16 + 4096 * 32) * sizeof(unsigned long long));
+#endif
 #undef ALLOC
     if (!rc) rc = setup_tables(e);
     if (rc) {
@@ -372,6 +377,10 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
     d.T_table = (const double *)e->T_table.p; d.log_table = (const float *)e->log_table.p;
     d.sqrt_table = (const double *)e->sqrt_table.p; d.noise_off = (const int *)e->noise_off.p;
     d.cnt = (unsigned long long *)e->cnt.p; d.next_game = (int *)e->next_game.p; d.active = (int *)e->active.p;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
+    }
     d.v2w[0] = d.v2w[1] = d.v2b[0] = d.v2b[1] = nullptr;
     const char *pe = getenv("AZ_PROFILE_EVENTS");
     e->profile = !(pe && pe[0] == '0');
@@ -392,7 +401,7 @@ extern "C" void az_destroy(az_engine *e)
     DevBuf *all[] = {&e->board, &e->s_game, &e->s_ply, &e->s_player, &e->s_last, &e->s_status, &e->s_net, &e->edges,
                      &e->rows_used, &e->path, &e->depth, &e->leaf_kind, &e->leaf, &e->leaf_last, &e->logits, &e->vhid,
                      &e->pol_feat, &e->val_feat, &e->T_table, &e->log_table, &e->sqrt_table, &e->noise_off, &e->cnt,
-                     &e->next_game, &e->active, &e->noise, &e->u, &e->rec_planes, &e->rec_last, &e->rec_action,
+                     &e->next_game, &e->active, &e->ticket, &e->noise, &e->u, &e->rec_planes, &e->rec_last, &e->rec_action,
                      &e->rec_mover, &e->rec_pi, &e->rec_visits, &e->g_nply, &e->g_result, &e->src_index};
     for (DevBuf *b : all) dev_free(*b);
     for (int s = 0; s < 2; s++) {
@@ -936,6 +945,16 @@ extern "C" int az_arena(az_engine *e, const az_arena_args *a, az_arena_result *o
         out->wins = w; out->losses = l; out->draws = dr; out->total = w + l + dr;
         out->win_rate = out->total ? (w + 0.5 * dr) / out->total : 0.0;     // evaluator.py:106-109
     }
+    return AZ_OK;
+}
+
+// diagnostic builds (-DAZ_STAMPS): per-workgroup phase stamps of the last k_trunk launch, 16 u64 per workgroup
+extern "C" int az_debug_stamps(az_engine *e, unsigned long long *out, int max_groups)
+{
+    if (!e || !out || !e->dbg.p) return AZ_ERR_STATE;
+    size_t n = std::min<size_t>((size_t)max_groups * 16, e->dbg.bytes / 8);
+    if (max_groups < 0) n = e->dbg.bytes / 8;   // everything (trunk stamps, then k_fc stamps at offset B*16)
+    HIPCHECK(e, hipMemcpy(out, e->dbg.p, n * 8, hipMemcpyDeviceToHost));
     return AZ_OK;
 }
 

@@ -11,30 +11,56 @@
 #pragma once
 #include "az_tree.h"
 
+#ifdef AZ_STAMPS
+// diagnostic build only: per-workgroup phase time stamps (s_memtime) into a buffer no other code reads
+#define AZ_STAMP(k) do { if (threadIdx.x == 0 && dbg) dbg[(size_t)grp * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AZ_STAMP(k) do { } while (0)
+#endif
+
+#ifndef AZ_NW
+#define AZ_NW 8          // waves per trunk workgroup
+#endif
+#ifndef AZ_NTW
+#define AZ_NTW 2         // channel tiles per wave in the conv layers
+#endif
+#ifndef AZ_SCHED
+#define AZ_SCHED 0       // 0: 1 MFMA : 1 LDS read interleave, 1: read burst then MFMA burst
+#endif
+
 struct NetWeights {
     // MFMA-fragment packed (see pack_* in az_engine.hip): [ntile][kstep/4][lane][4]
     const float *c1, *c2, *c3, *hd, *pf, *vf;
     const float *c1b, *c2b, *c3b, *hdb, *pfb, *vfb;   // biases (hdb: 4 policy_conv + 2 value_conv)
 };
 
-__host__ __device__ constexpr int up17(int x) { return x + ((17 - (x % 32) + 32) % 32); }
+__host__ __device__ constexpr int up16(int x) { return x + ((16 - (x % 32) + 32) % 32); }   // smallest y >= x, y == 16 (mod 32)
 
 template <int N>
 struct NetGeo {
     static constexpr int n = N, nn = N * N, PW = N + 2, PP = PW * PW;
     static constexpr int G = N == 15 ? 1 : (N == 9 ? 3 : 7);     // boards per workgroup
-    static constexpr int M = G * nn;                               // real GEMM rows (board cells)
-    static constexpr int MT = (M + 15) / 16, MR = MT * 16;         // 16-row MFMA tiles
-    static constexpr int CS = up17(G * PP);                        // channel stride of padded planes (floats)
-    static constexpr int CS3 = up17(MR);                           // channel stride of the conv3 output image
+    static constexpr int M = G * nn;                               // real GEMM columns (board cells)
+    // 16-cell MFMA tiles.  n = 15: one tile = one board row + its right padding cell (contiguous in the padded
+    // image, so the 16 lanes of a fragment hit 16 consecutive LDS banks); other sizes: 16 consecutive cells.
+    static constexpr bool ROWT = (N == 15);
+    static constexpr int MT = ROWT ? G * N : (M + 15) / 16, MR = MT * 16;
+    static constexpr int CS = up16(G * PP);                        // channel stride of padded planes (floats), == 16 mod 32
+    static constexpr int CS3 = up16(MR);                           // channel stride of the conv3 output image
     static constexpr int LDSF = (96 * CS > 128 * CS3) ? 96 * CS : 128 * CS3;
     static constexpr int RW = ((nn + 63) / 64) * 64;
     // FC kernel
     static constexpr int NTP = (nn + 15) / 16;                     // policy N-tiles
     static constexpr int KSP = nn;                                 // policy k-steps (4nn / 4)
     static constexpr int KSV = (2 * nn + 3) / 4;                   // value_fc1 k-steps
-    static constexpr int FSTR = up17(6 * nn + 4);                  // LDS row stride of the feature tile
-    static constexpr int NSPLIT = (NTP + 4 + 3) / 4;
+    static constexpr int FROW = ((6 * nn + 3) / 4) * 4;            // feature row in HBM: [0,4nn) policy, [4nn,6nn) value, zero tail
+    static constexpr int KS4P_PAD = (((KSP + 3) / 4 + 15) / 16) * 16;   // policy weight groups padded to chunks of 16
+    static constexpr int KS4V_PAD = (((KSV + 3) / 4 + 15) / 16) * 16;
+    static constexpr int FNEED = (KS4P_PAD * 16 > 4 * nn + KS4V_PAD * 16) ? KS4P_PAD * 16 : 4 * nn + KS4V_PAD * 16;
+    static constexpr int FSTR0 = FROW > FNEED ? FROW : FNEED;     // the padded k-steps read (zero) LDS beyond the row
+    static constexpr int FSTR = FSTR0 + ((4 - (FSTR0 % 32) + 32) % 32);   // LDS row stride, == 4 (mod 32), multiple of 4
+    static constexpr int FCW = 8;                                  // waves per k_fc workgroup (one 16x16 output tile each)
+    static constexpr int NSPLIT = (NTP + 4 + FCW - 1) / FCW;       // workgroups per 16-board row: (B/16)*NSPLIT <= 256 -> one round
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
@@ -42,96 +68,178 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// One conv layer on the workgroup's LDS image.  OUT3=false: write relu(acc+bias) into the next padded image.
-// OUT3=true (conv3): barrier, then write into the [co][m] image that overlays the (now dead) inputs.
+// LDS activation image of a conv input with C >= 16 channels ("packed"): channel ci = 16*cg + 4*e + q lives at
+//   float index  (((cg*4 + q) * CS + pos) * 4 + e)
+// so that ONE ds_read_b128 at (cg, q, pos) delivers the B-operand values of four consecutive k-steps
+// (e = 0..3) of lane group q, and the 16 lanes of a group read 256 contiguous bytes (conflict-free; CS % 16 == 0).
+template <int N>
+__device__ __forceinline__ int pk_index(int ci, int pos)
+{
+    return ((((ci >> 4) * 4 + (ci & 3)) * NetGeo<N>::CS + pos) << 2) + ((ci >> 2) & 3);
+}
+
+// One conv layer on the workgroup's LDS image, computed as D[co][cell] = sum_k W[co][k] * X[k][cell]:
+// the weight fragment is the MFMA A operand (row = output channel), the activation fragment the B operand
+// (column = board cell), so an accumulator register holds 16 consecutive cells of one channel per 16 lanes.
+// A wave owns NTW channel tiles x MTW cell tiles; every activation fragment read from LDS feeds NTW MFMAs.
+// CIN == 4 (conv1) reads plain planes [ci][pos]; CIN >= 32 reads the packed image above.
+// OUT3=false: relu(acc+bias) -> packed image of the next layer.  OUT3=true (conv3): barrier, then the
+// [co][cell] image that overlays the (now dead) inputs.
 template <int N, int CIN, int COUT, bool OUT3>
 __device__ __forceinline__ void conv_layer(const float *in, float *out, const float *__restrict__ wp,
-                                           const float *__restrict__ bias, const unsigned short *wpos, int wave,
-                                           int lane)
+                                           const float *__restrict__ bias, const unsigned short *wpos,
+                                           const unsigned short *cellof, int wave, int lane)
 {
     typedef NetGeo<N> G;
-    constexpr int NT = COUT / 16;          // N tiles
-    constexpr int MG = 8 / NT;             // M groups (8 waves)
+    constexpr int NT = COUT / 16;                              // channel tiles
+    constexpr int NTW = (AZ_NTW <= NT) ? AZ_NTW : NT;          // channel tiles per wave
+    constexpr int NG = NT / NTW;                               // channel-tile groups
+    constexpr int MG = (AZ_NW / NG) > 0 ? (AZ_NW / NG) : 1;    // cell-tile groups
     constexpr int MTW = (G::MT + MG - 1) / MG;
     constexpr int KST = CIN / 4;           // k-steps per tap
     constexpr int KS = 9 * KST;
     constexpr int KS4 = (KS + 3) / 4;
-    const int nt = wave % NT, mg = wave / NT;
+    const int ng = wave % NG, mg = wave / NG;       // wave is wave-uniform (readfirstlane) -> scalar control flow
     const int q = lane >> 4, r16 = lane & 15;
 
-    int rb[MTW];
+    f32x4 acc[NTW][MTW];
 #pragma unroll
-    for (int i = 0; i < MTW; i++) {
-        int mt = mg + i * MG;
-        int m = (mt < G::MT ? mt : 0) * 16 + r16;
-        rb[i] = (int)wpos[m] - (G::PW + 1) + q * G::CS;
-    }
-    f32x4 acc[MTW];
+    for (int t = 0; t < NTW; t++)
 #pragma unroll
-    for (int i = 0; i < MTW; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MTW; i++) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const float4 *wp4 = reinterpret_cast<const float4 *>(wp) + (size_t)nt * KS4 * 64 + lane;
+    const float4 *wp4[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; t++) wp4[t] = reinterpret_cast<const float4 *>(wp) + (size_t)(ng * NTW + t) * KS4 * 64 + lane;
     if constexpr (CIN == 4) {
-        // conv1: 9 k-steps (one per tap), channels = {mover, opponent, last move, zero plane}
-        float4 b0 = wp4[0], b1 = wp4[64], b2 = wp4[128];
-        float bk[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+        // conv1: 9 k-steps (one per tap), channels = {mover, opponent, last move, zero plane}, planes [ci][pos]
+        int rb[MTW];
 #pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            const int toff = (tap / 3) * G::PW + (tap % 3);
-#pragma unroll
-            for (int i = 0; i < MTW; i++)
-                if (mg + i * MG < G::MT) acc[i] = mfma4(in[rb[i] + toff], bk[tap], acc[i]);
+        for (int i = 0; i < MTW; i++) {
+            int mt = mg + i * MG;
+            int m = (mt < G::MT ? mt : mg) * 16 + r16;      // a surplus tile aliases the first one (never written back)
+            rb[i] = (int)wpos[m] - (G::PW + 1) + q * G::CS;
         }
-    } else {
-        constexpr int NQ = KST / 4;        // float4 weight groups per tap
-        float4 bq = wp4[0];
+        float bk[NTW][12];
+#pragma unroll
+        for (int t = 0; t < NTW; t++) {
+            float4 b0 = wp4[t][0], b1 = wp4[t][64], b2 = wp4[t][128];
+            const float tmp[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+            for (int j = 0; j < 12; j++) bk[t][j] = tmp[j];
+        }
+#pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int toff = (tap / 3) * G::PW + (tap % 3);
-            for (int sq = 0; sq < NQ; sq++) {
-                const int it = tap * NQ + sq;
-                const float4 bn = wp4[(size_t)(it + 1 < 9 * NQ ? it + 1 : it) * 64];
-                const float *ip = in + toff + sq * 16 * G::CS;
-                const float be[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
+            for (int i = 0; i < MTW; i++) {
+                const float a = in[rb[i] + toff];
 #pragma unroll
-                    for (int i = 0; i < MTW; i++)
-                        if (mg + i * MG < G::MT) acc[i] = mfma4(ip[rb[i] + e * 4 * G::CS], be[e], acc[i]);
-                }
-                bq = bn;
+                for (int t = 0; t < NTW; t++) acc[t][i] = mfma4(bk[t][tap], a, acc[t][i]);
             }
         }
+    } else {
+        constexpr int NQ = KST / 4;        // weight groups (= 16-channel groups) per tap: 2 for conv2, 4 for conv3
+        // Software pipeline pinned with sched_group_barrier: while the 4*MTW*NTW MFMAs of group g issue, the MTW
+        // ds_read_b128 of group g+1 are interleaved between them; the weight fragments of tap t+1 are fetched (L2)
+        // at the top of tap t.
+        const float4 *in4 = reinterpret_cast<const float4 *>(in);
+        int ra[MTW];                       // running float4 index: (cg*4 + q)*CS + top-left position of the window
+#pragma unroll
+        for (int i = 0; i < MTW; i++) {
+            int mt = mg + i * MG;
+            int m = (mt < G::MT ? mt : mg) * 16 + r16;
+            ra[i] = (int)wpos[m] - (G::PW + 1) + q * G::CS;
+        }
+        float4 a0[MTW], a1[MTW];
+        float4 bw[NTW][NQ], bnx[NTW][NQ];
+#pragma unroll
+        for (int t = 0; t < NTW; t++)
+#pragma unroll
+            for (int j = 0; j < NQ; j++) bw[t][j] = wp4[t][(size_t)j * 64];
+#pragma unroll
+        for (int i = 0; i < MTW; i++) a0[i] = in4[ra[i]];
+        for (int tap = 0; tap < 9; tap++) {
+            const int tn = tap + 1 < 9 ? tap + 1 : tap;
+#pragma unroll
+            for (int t = 0; t < NTW; t++)
+#pragma unroll
+                for (int j = 0; j < NQ; j++) bnx[t][j] = wp4[t][(size_t)(tn * NQ + j) * 64];
+            // float4-index step from the last group of this tap to the first group of the next tap
+            const int dnext = ((tn / 3) * G::PW + (tn % 3)) - ((tap / 3) * G::PW + (tap % 3)) - (NQ - 1) * 4 * G::CS;
+#pragma unroll
+            for (int sq = 0; sq < NQ; sq++) {
+                float4 *cur = (sq & 1) ? a1 : a0;
+                float4 *nxt = (sq & 1) ? a0 : a1;
+                const int dstep = sq + 1 < NQ ? 4 * G::CS : dnext;
+#pragma unroll
+                for (int i = 0; i < MTW; i++) { ra[i] += dstep; nxt[i] = in4[ra[i]]; }
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int i = 0; i < MTW; i++)
+#pragma unroll
+                        for (int t = 0; t < NTW; t++) {
+                            const float4 wv = bw[t][sq];
+                            const float we = e == 0 ? wv.x : e == 1 ? wv.y : e == 2 ? wv.z : wv.w;
+                            const float ae = e == 0 ? cur[i].x : e == 1 ? cur[i].y : e == 2 ? cur[i].z : cur[i].w;
+                            acc[t][i] = mfma4(we, ae, acc[t][i]);
+                        }
+#pragma unroll
+                for (int i = 0; i < MTW; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NTW, 0);   // 4*NTW MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // 1 LDS read (b128)
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NTW; t++)
+#pragma unroll
+                for (int j = 0; j < NQ; j++) bw[t][j] = bnx[t][j];
+        }
     }
-    const int co = nt * 16 + r16;
-    const float bco = bias[co];
     if constexpr (OUT3) __syncthreads();   // every wave has finished reading the conv3 input image
 #pragma unroll
-    for (int i = 0; i < MTW; i++) {
-        int mt = mg + i * MG;
-        if (mt < G::MT) {
+    for (int t = 0; t < NTW; t++) {
+        const int nt = ng * NTW + t;
+        float bco[4];
 #pragma unroll
-            for (int rg = 0; rg < 4; rg++) {
-                int m = mt * 16 + q * 4 + rg;
-                float v = acc[i][rg] + bco;
-                v = v > 0.0f ? v : 0.0f;
-                if constexpr (OUT3) out[co * G::CS3 + m] = v;
-                else if (m < G::M) out[co * G::CS + wpos[m]] = v;
+        for (int rg = 0; rg < 4; rg++) bco[rg] = bias[nt * 16 + q * 4 + rg];
+#pragma unroll
+        for (int i = 0; i < MTW; i++) {
+            const int mt = mg + i * MG;
+            if (mt < G::MT) {
+                const int m = mt * 16 + r16;
+                const bool valid = cellof[m] != 0xFFFFu;
+                const int pos = wpos[m];
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) {
+                    const int co = nt * 16 + q * 4 + rg;      // = 16*cg + 4*e + q' with cg = nt, e = q, q' = rg
+                    float v = acc[t][i][rg] + bco[rg];
+                    v = v > 0.0f ? v : 0.0f;
+                    if constexpr (OUT3) out[co * G::CS3 + m] = v;
+                    else if (valid) out[pk_index<N>(co, pos)] = v;
+                }
             }
         }
     }
 }
 
 template <int N>
-__global__ __launch_bounds__(512) void k_trunk(DevState d, NetWeights w, int net_id, float *__restrict__ pol_feat,
-                                               float *__restrict__ val_feat)
+__global__ __launch_bounds__(AZ_NW * 64) void k_trunk(DevState d, NetWeights w, int net_id, float *__restrict__ feat,
+                                               unsigned long long *dbg)
 {
     typedef NetGeo<N> G;
     __shared__ __attribute__((aligned(16))) float lds[G::LDSF];
-    __shared__ unsigned short wpos[G::MR];
+    __shared__ unsigned short wpos[G::MR];     // centre position of tile cell m in the padded image
+    __shared__ unsigned short cellof[G::MR];   // g*nn + cell index, 0xFFFF for a junk lane
     __shared__ int any_active;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b0 = blockIdx.x * G::G;
-
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // One workgroup per board group.  (A persistent grid-stride / ticket variant measured 6 % slower: 256 CUs marching
+    // through identical phases in lock step lose the overlap that the dispatcher's natural skew provides.)
+    const int grp = blockIdx.x;
+    const int b0 = grp * G::G;
+    AZ_STAMP(0);
     if (tid == 0) any_active = 0;
     __syncthreads();
     if (tid < G::G) {
@@ -150,111 +258,191 @@ __global__ __launch_bounds__(512) void k_trunk(DevState d, NetWeights w, int net
     // zero both padded images (the padding ring must read as 0)
     {
         float4 *z = reinterpret_cast<float4 *>(lds);
-        for (int i = tid; i < (96 * G::CS) / 4; i += 512) z[i] = float4{0.f, 0.f, 0.f, 0.f};
-        if (tid < (96 * G::CS) % 4) lds[(96 * G::CS) - 1 - tid] = 0.0f;
+        for (int i = tid; i < (96 * G::CS) / 4; i += AZ_NW * 64) z[i] = float4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int m = tid; m < G::MR; m += 512) {
-        int g = m / G::nn, p = m - g * G::nn;
-        int r = p / N, c = p - r * N;
-        wpos[m] = (unsigned short)(m < G::M ? g * G::PP + (r + 1) * G::PW + (c + 1) : G::PW + 1);
+    for (int m = tid; m < G::MR; m += AZ_NW * 64) {
+        int pos, cell;
+        if constexpr (G::ROWT) {
+            const int t = m >> 4, c = m & 15, g = t / N, r = t - g * N;
+            pos = g * G::PP + (r + 1) * G::PW + (c + 1);                 // c == N is the right padding cell of the row
+            cell = c < N ? g * G::nn + r * N + c : 0xFFFF;
+        } else {
+            const int g = m / G::nn, p = m - g * G::nn, r = p / N, c = p - r * N;
+            pos = m < G::M ? g * G::PP + (r + 1) * G::PW + (c + 1) : G::PW + 1;
+            cell = m < G::M ? m : 0xFFFF;
+        }
+        wpos[m] = (unsigned short)pos;
+        cellof[m] = (unsigned short)cell;
     }
     __syncthreads();
     // games.py:86-129 encode: ch0 = side to move, ch1 = opponent, ch2 = last action, ch3 = zeros
-    for (int m = tid; m < G::M; m += 512) {
-        int g = m / G::nn, p = m - g * G::nn;
-        int b = b0 + g;
-        if (b < d.B) {
-            const u64 *lf = d.leaf + (size_t)b * 8;
-            bool me = (lf[p >> 6] >> (p & 63)) & 1ull;
-            bool op = (lf[4 + (p >> 6)] >> (p & 63)) & 1ull;
-            int pos = wpos[m];
-            if (me) inB[pos] = 1.0f;
-            if (op) inB[G::CS + pos] = 1.0f;
-            if (d.leaf_last[b] == p) inB[2 * G::CS + pos] = 1.0f;
+    for (int m = tid; m < G::MR; m += AZ_NW * 64) {
+        const int cell = cellof[m];
+        if (cell != 0xFFFF) {
+            const int g = cell / G::nn, p = cell - g * G::nn;
+            const int b = b0 + g;
+            if (b < d.B) {
+                const u64 *lf = d.leaf + (size_t)b * 8;
+                const bool me = (lf[p >> 6] >> (p & 63)) & 1ull;
+                const bool op = (lf[4 + (p >> 6)] >> (p & 63)) & 1ull;
+                const int pos = wpos[m];
+                if (me) inB[pos] = 1.0f;
+                if (op) inB[G::CS + pos] = 1.0f;
+                if (d.leaf_last[b] == p) inB[2 * G::CS + pos] = 1.0f;
+            }
         }
     }
     __syncthreads();
-    conv_layer<N, 4, 32, false>(inB, inA, w.c1, w.c1b, wpos, wave, lane);
+    AZ_STAMP(1);
+    conv_layer<N, 4, 32, false>(inB, inA, w.c1, w.c1b, wpos, cellof, wave, lane);
     __syncthreads();
-    conv_layer<N, 32, 64, false>(inA, inB, w.c2, w.c2b, wpos, wave, lane);
+    // the input planes lived in the first 3 planes of inB; clear them before conv2's packed output lands there
+    // (in packed coordinates some of those floats are padding-ring cells that conv2 never writes)
+    for (int i = tid; i < 3 * G::CS; i += AZ_NW * 64) inB[i] = 0.0f;
     __syncthreads();
-    conv_layer<N, 64, 128, true>(inB, lds, w.c3, w.c3b, wpos, wave, lane);
+    AZ_STAMP(2);
+    conv_layer<N, 32, 64, false>(inA, inB, w.c2, w.c2b, wpos, cellof, wave, lane);
     __syncthreads();
-    // policy_conv (128->4) and value_conv (128->2), 1x1, as one 16-column MFMA GEMM over the conv3 image
+    AZ_STAMP(3);
+    conv_layer<N, 64, 128, true>(inB, lds, w.c3, w.c3b, wpos, cellof, wave, lane);
+    __syncthreads();
+    AZ_STAMP(4);
+    // policy_conv (128->4) and value_conv (128->2), 1x1: D[head channel][cell] over the conv3 image, 32 k-steps
     {
         const int q = lane >> 4, r16 = lane & 15;
         const float4 *wp4 = reinterpret_cast<const float4 *>(w.hd) + lane;
-        const float hb = r16 < 6 ? w.hdb[r16] : 0.0f;
-        for (int mt = wave; mt < G::MT; mt += 8) {
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float *ip = lds + q * G::CS3 + mt * 16 + r16;
+        float hb[4];
 #pragma unroll
-            for (int s4 = 0; s4 < 8; s4++) {
-                float4 bq = wp4[s4 * 64];
-                acc = mfma4(ip[(s4 * 16 + 0) * G::CS3], bq.x, acc);
-                acc = mfma4(ip[(s4 * 16 + 4) * G::CS3], bq.y, acc);
-                acc = mfma4(ip[(s4 * 16 + 8) * G::CS3], bq.z, acc);
-                acc = mfma4(ip[(s4 * 16 + 12) * G::CS3], bq.w, acc);
-            }
+        for (int rg = 0; rg < 4; rg++) hb[rg] = (q * 4 + rg) < 6 ? w.hdb[q * 4 + rg] : 0.0f;
+        constexpr int HT = (G::MT + AZ_NW - 1) / AZ_NW;     // tiles per wave
+        f32x4 acc[HT];
+        const float *ip[HT];
 #pragma unroll
-            for (int rg = 0; rg < 4; rg++) {
-                int m = mt * 16 + q * 4 + rg;
-                if (m < G::M && r16 < 6) {
-                    int g = m / G::nn, p = m - g * G::nn;
-                    int b = b0 + g;
+        for (int i = 0; i < HT; i++) {
+            const int mt = wave + AZ_NW * i;
+            acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ip[i] = lds + q * G::CS3 + (mt < G::MT ? mt : wave) * 16 + r16;
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 8; s4++) {
+            const float4 bq = wp4[s4 * 64];
+            const float be[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int i = 0; i < HT; i++) acc[i] = mfma4(be[e], ip[i][(s4 * 16 + 4 * e) * G::CS3], acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < HT; i++) {
+            const int mt = wave + AZ_NW * i;
+            if (mt < G::MT) {
+                const int cell = cellof[mt * 16 + r16];
+                if (cell != 0xFFFF) {
+                    const int g = cell / G::nn, p = cell - g * G::nn;
+                    const int b = b0 + g;
                     if (b < d.B && d.s_net[b] == net_id) {
-                        float v = acc[rg] + hb;
-                        v = v > 0.0f ? v : 0.0f;
-                        if (r16 < 4) pol_feat[(size_t)b * 4 * G::nn + r16 * G::nn + p] = v;
-                        else val_feat[(size_t)b * 2 * G::nn + (r16 - 4) * G::nn + p] = v;
+#pragma unroll
+                        for (int rg = 0; rg < 4; rg++) {
+                            const int j = q * 4 + rg;     // head channel: 0-3 policy_conv, 4-5 value_conv (net.py:64,69 flatten order)
+                            if (j < 6) {
+                                float v = acc[i][rg] + hb[rg];
+                                feat[(size_t)b * G::FROW + j * G::nn + p] = v > 0.0f ? v : 0.0f;
+                            }
+                        }
                     }
                 }
             }
         }
     }
+    AZ_STAMP(5);
 }
 
 // policy_fc (net.py:65) and value_fc1 + ReLU (net.py:69) for 16 boards per workgroup row.
 template <int N>
-__global__ __launch_bounds__(256) void k_fc(DevState d, NetWeights w, int net_id, const float *__restrict__ pol_feat,
-                                            const float *__restrict__ val_feat)
+__global__ __launch_bounds__(NetGeo<N>::FCW * 64) void k_fc(DevState d, NetWeights w, int net_id, const float *__restrict__ feat,
+                                                            unsigned long long *dbgfc)
 {
     typedef NetGeo<N> G;
     __shared__ __attribute__((aligned(16))) float ft[16 * G::FSTR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mb = blockIdx.x * 16;
-    const int tile = blockIdx.y * 4 + wave;
-    // stage the 16 boards' features: [i][0..4nn) policy features, [4nn..6nn) value features, zero tail
-    for (int idx = tid; idx < 16 * G::FSTR; idx += 256) {
-        int i = idx / G::FSTR, k = idx - i * G::FSTR;
-        int b = mb + i;
-        float v = 0.0f;
-        if (b < d.B) {
-            if (k < 4 * G::nn) v = pol_feat[(size_t)b * 4 * G::nn + k];
-            else if (k < 6 * G::nn) v = val_feat[(size_t)b * 2 * G::nn + (k - 4 * G::nn)];
-        }
-        ft[idx] = v;
+    const int tile = blockIdx.y * G::FCW + wave;
+    // stage the 16 boards' feature rows (16-byte vectors; rows are FROW floats, 16-B aligned)
+#ifdef AZ_STAMPS
+#define FC_STAMP(k) do { if (dbgfc && (threadIdx.x & 63) == 0) dbgfc[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FC_STAMP(k) do { } while (0)
+#endif
+    FC_STAMP(0);
+    // the LDS tail [FROW, FSTR) is zeroed: the padded k-steps of the last weight group read it (times zero weights)
+    constexpr int V = G::FROW / 4, VS = G::FSTR / 4;
+    static_assert(G::FNEED <= G::FSTR, "feature tile too narrow");
+    constexpr int NTH = G::FCW * 64;
+    constexpr int U = (16 * VS + NTH - 1) / NTH;
+    float4 tmp[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {            // all loads in flight before the first LDS store
+        const int idx = tid + NTH * u;
+        const int i = idx / VS, c = idx - i * VS;
+        const int b = mb + i;
+        tmp[u] = float4{0.f, 0.f, 0.f, 0.f};
+        if (idx < 16 * VS && b < d.B && c < V) tmp[u] = reinterpret_cast<const float4 *>(feat + (size_t)b * G::FROW)[c];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int idx = tid + NTH * u;
+        const int i = idx / VS, c = idx - i * VS;
+        if (idx < 16 * VS) reinterpret_cast<float4 *>(ft + i * G::FSTR)[c] = tmp[u];
     }
     __syncthreads();
+    FC_STAMP(1);
     if (tile >= G::NTP + 4) return;
     const int q = lane >> 4, r16 = lane & 15;
     const bool is_pol = tile < G::NTP;
     const int KS = is_pol ? G::KSP : G::KSV;
     const int KS4 = (KS + 3) / 4;
+    constexpr int CH = 8;                              // weight groups (of 4 k-steps) per chunk
+    const int NCH = (KS4 + CH - 1) / CH;               // the packed weights are zero-padded to whole chunks of 16 groups
     const float4 *wp4 = reinterpret_cast<const float4 *>(is_pol ? w.pf : w.vf) +
-                        (size_t)(is_pol ? tile : tile - G::NTP) * KS4 * 64 + lane;
+                        (size_t)(is_pol ? tile : tile - G::NTP) * (is_pol ? G::KS4P_PAD : G::KS4V_PAD) * 64 + lane;
     const float *ip = ft + r16 * G::FSTR + (is_pol ? 0 : 4 * G::nn) + q;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    float4 bq = wp4[0];
-    for (int s4 = 0; s4 < KS4; s4++) {
-        const float4 bn = wp4[(size_t)(s4 + 1 < KS4 ? s4 + 1 : s4) * 64];
-        const int s = s4 * 4;
-        acc = mfma4(ip[(s + 0) * 4], bq.x, acc);
-        if (s + 1 < KS) acc = mfma4(ip[(s + 1) * 4], bq.y, acc);
-        if (s + 2 < KS) acc = mfma4(ip[(s + 2) * 4], bq.z, acc);
-        if (s + 3 < KS) acc = mfma4(ip[(s + 3) * 4], bq.w, acc);
-        bq = bn;
+    // One k-ordered MFMA chain.  Both operand streams are double-buffered a whole chunk (32 MFMAs) ahead: the
+    // weight fragments come from L2, the feature fragments from LDS; the sched_barrier pins the loads above the chain.
+    float4 bcur[CH], bnxt[CH];
+    float acur[CH][4], anxt[CH][4];
+#pragma unroll
+    for (int j = 0; j < CH; j++) {
+        bcur[j] = wp4[(size_t)j * 64];
+#pragma unroll
+        for (int e = 0; e < 4; e++) acur[j][e] = ip[j * 16 + e * 4];
     }
+    for (int c = 0; c < NCH; c++) {
+        const int cn = c + 1 < NCH ? c + 1 : c;
+        const float *ipn = ip + cn * CH * 16;
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            bnxt[j] = wp4[(size_t)(cn * CH + j) * 64];
+#pragma unroll
+            for (int e = 0; e < 4; e++) anxt[j][e] = ipn[j * 16 + e * 4];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            acc = mfma4(acur[j][0], bcur[j].x, acc);
+            acc = mfma4(acur[j][1], bcur[j].y, acc);
+            acc = mfma4(acur[j][2], bcur[j].z, acc);
+            acc = mfma4(acur[j][3], bcur[j].w, acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            bcur[j] = bnxt[j];
+#pragma unroll
+            for (int e = 0; e < 4; e++) acur[j][e] = anxt[j][e];
+        }
+    }
+    FC_STAMP(2);
 #pragma unroll
     for (int rg = 0; rg < 4; rg++) {
         int b = mb + q * 4 + rg;

@@ -151,39 +151,69 @@ __global__ void k_begin(DevState d)
 
 // ------------------------------------------------------------------------------------------------
 // k_step: consume the evaluation of the pending leaf (expand + backup), then select the next leaf.
+// Latency-bound (one wave per game, ~4 waves per CU): every load that does not depend on another load is
+// issued up front in one round trip; the sqrt table lives in LDS; the chosen edge is broadcast by shuffle.
+// Dynamic LDS: (S + 2) doubles.
 // ------------------------------------------------------------------------------------------------
 template <int N, bool SYNTH>
 __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_select)
 {
     typedef TreeGeo<N> G;
+    extern __shared__ double sq_lds[];                 // np.sqrt(N + 1e-8), N = 0..S+1 (mcts.py:73)
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= d.B) return;
-    if (d.s_status[b] != SLOT_ACTIVE) return;
-    const int kind = d.leaf_kind[b];
+    const bool inb = b < d.B;
+    const int bb = inb ? b : 0;
+    for (int i = threadIdx.x; i < d.S + 2; i += 256) sq_lds[i] = d.sqrt_table[i];
+
+    // ---- independent loads, all in flight together ----
+    const int status = d.s_status[bb];
+    const int kind = d.leaf_kind[bb];
+    const int depth0 = d.depth[bb];
+    const int rows0 = d.rows_used[bb];
+    const int pl = d.s_player[bb];
+    const int slast = d.s_last[bb];
+    const int netid = d.s_net[bb];
+    const int leaf_last = d.leaf_last[bb];
+    const int game = d.s_game[bb];
+    const int ply = d.s_ply[bb];
+    const Plane lme = pl_load(d.leaf + (size_t)bb * 8), lopp = pl_load(d.leaf + (size_t)bb * 8 + 4);
+    const Plane bX = pl_load(d.board + (size_t)bb * 8), bO = pl_load(d.board + (size_t)bb * 8 + 4);
+    unsigned *path = d.path + (size_t)bb * G::PATH;
+    const unsigned path_l = path[lane];                // PATH = n*n+1 >= 26 entries; lanes beyond read a neighbour's slot (unused)
+    float x[G::CPL];
+    float h_l = 0.0f, w2a = 0.0f, w2b = 0.0f, b2a = 0.0f, b2b = 0.0f;
+    if (!SYNTH) {
+        const float *lg = d.logits + (size_t)bb * G::RW;
+#pragma unroll
+        for (int i = 0; i < G::CPL; i++) x[i] = lg[lane + 64 * i];
+        h_l = d.vhid[(size_t)bb * 64 + lane];
+        w2a = d.v2w[0][lane];
+        b2a = d.v2b[0][0];
+        if (d.v2w[1]) { w2b = d.v2w[1][lane]; b2b = d.v2b[1][0]; }
+    }
+    __syncthreads();
+    if (!inb || status != SLOT_ACTIVE) return;
     Edge *rows = d.edges + (size_t)b * d.R * G::RW;
-    unsigned *path = d.path + (size_t)b * G::PATH;
 
     // ---------------- stage 1: evaluation -> expand -> backup ----------------
     if (kind != LEAF_NONE) {
         float v = 0.0f;
         if (kind == LEAF_ROOT || kind == LEAF_EXPAND) {
-            Plane me = pl_load(d.leaf + (size_t)b * 8), opp = pl_load(d.leaf + (size_t)b * 8 + 4);
             float P[G::CPL];
             if (SYNTH) {
                 // build-owned deterministic evaluator (test hook behind the policy_value_fn seam, mcts.py:87-93)
-                int last = d.leaf_last[b];
                 unsigned hx = 0;
 #pragma unroll
                 for (int i = 0; i < G::CPL; i++) {
                     int j = lane + 64 * i;
                     if (j < G::nn) {
-                        unsigned code = pl_get(me, j) ? 1u : (pl_get(opp, j) ? 2u : 0u);
+                        unsigned code = pl_get(lme, j) ? 1u : (pl_get(lopp, j) ? 2u : 0u);
                         hx ^= az_fmix32((unsigned)j * 3u + code + 0x9E3779B9u);
                     }
                 }
                 unsigned hs = wave_xor_u(hx);
-                hs ^= az_fmix32(0x51ED270Bu + (unsigned)(last + 1));
+                hs ^= az_fmix32(0x51ED270Bu + (unsigned)(leaf_last + 1));
 #pragma unroll
                 for (int i = 0; i < G::CPL; i++) {
                     int j = lane + 64 * i;
@@ -193,15 +223,39 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
                 int vv = (int)(az_fmix32(hs ^ 0x7F4A7C15u) & 0x1FFu);
                 v = (float)(vv - 256) / 256.0f;
             } else {
-                eval_tail<N>(d, b, lane, P, v);
+                // controller.py:49 softmax over all n^2 logits (no legality mask), canonical wave order
+                float mx = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < G::CPL; i++) {
+                    if (lane + 64 * i >= G::nn) x[i] = -INFINITY;
+                    mx = fmaxf(mx, x[i]);
+                }
+                mx = wave_max_f(mx);
+                float part = 0.0f;
+#pragma unroll
+                for (int i = 0; i < G::CPL; i++) {
+                    P[i] = 0.0f;
+                    if (lane + 64 * i < G::nn) {
+                        P[i] = az_expf(x[i] - mx);
+                        part = part + P[i];
+                    }
+                }
+                const float ssum = wave_sum_butterfly(part);
+#pragma unroll
+                for (int i = 0; i < G::CPL; i++) P[i] = P[i] / ssum;
+                // value tail: value_fc2 + tanh (net.py:70), one k-ordered fma chain over the lane-held operands
+                const float w2_l = netid ? w2b : w2a;
+                float acc = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 64; i++) acc = __builtin_fmaf(__shfl(h_l, i, 64), __shfl(w2_l, i, 64), acc);
+                v = az_tanhf(acc + (netid ? b2b : b2a));
             }
             if (kind == LEAF_ROOT && d.add_noise) {
                 // mcts.py:113-116; float32 multiply, float64 add, float32 store
                 Plane occ;
 #pragma unroll
-                for (int q = 0; q < 4; q++) occ.w[q] = me.w[q] | opp.w[q];
-                int g = d.s_game[b];
-                const double *nz = d.noise + (size_t)g * d.noise_stride + d.noise_off[d.s_ply[b]];
+                for (int q = 0; q < 4; q++) occ.w[q] = lme.w[q] | lopp.w[q];
+                const double *nz = d.noise + (size_t)game * d.noise_stride + d.noise_off[ply];
 #pragma unroll
                 for (int i = 0; i < G::CPL; i++) {
                     int j = lane + 64 * i;
@@ -213,7 +267,7 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
                 }
             }
             // mcts.py:50-64 expand: one edge per cell (occupied cells are never selected)
-            int row = kind == LEAF_ROOT ? 0 : d.rows_used[b];
+            const int row = kind == LEAF_ROOT ? 0 : rows0;
 #pragma unroll
             for (int i = 0; i < G::CPL; i++) {
                 int j = lane + 64 * i;
@@ -221,22 +275,19 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
                 e.W = 0.0; e.P = P[i]; e.N = 0; e.child = 0;
                 rows[(size_t)row * G::RW + j] = e;
             }
-            if (lane == 0) {
-                d.rows_used[b] = row + 1;
-                if (kind == LEAF_EXPAND) {
-                    unsigned pe = path[d.depth[b] - 1];
-                    rows[(size_t)(pe >> 16) * G::RW + (pe & 0xFFFFu)].child = (unsigned short)row;
-                }
+            if (lane == 0) d.rows_used[b] = row + 1;
+            if (kind == LEAF_EXPAND) {
+                const unsigned pe = depth0 - 1 < 64 ? (unsigned)__shfl((int)path_l, depth0 - 1, 64) : path[depth0 - 1];
+                if (lane == 0) rows[(size_t)(pe >> 16) * G::RW + (pe & 0xFFFFu)].child = (unsigned short)row;
             }
         }
         if (kind != LEAF_ROOT) {
             // mcts.py:132-134,141,76-82: value w.r.t. the side to move at the leaf, backed up with alternating sign
-            double value = kind == LEAF_EXPAND ? (double)v : (kind == LEAF_TERM_LOSS ? -1.0 : 0.0);
-            int depth = d.depth[b];
-            for (int dd = lane; dd < depth; dd += 64) {
-                unsigned pe = path[dd];
+            const double value = kind == LEAF_EXPAND ? (double)v : (kind == LEAF_TERM_LOSS ? -1.0 : 0.0);
+            for (int dd = lane; dd < depth0; dd += 64) {
+                const unsigned pe = dd < 64 ? path_l : path[dd];
                 Edge *e = rows + (size_t)(pe >> 16) * G::RW + (pe & 0xFFFFu);
-                double val = ((depth - 1 - dd) & 1) ? value : -value;
+                const double val = ((depth0 - 1 - dd) & 1) ? value : -value;
                 e->N = (unsigned short)(e->N + 1);
                 e->W = e->W + val;
             }
@@ -245,7 +296,7 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
                 c[0] += kind == LEAF_EXPAND ? 1ull : 0ull;
                 c[1] += 1ull;
                 c[2] += kind == LEAF_EXPAND ? 0ull : 1ull;
-                c[3] += (unsigned long long)depth;
+                c[3] += (unsigned long long)depth0;
             }
         }
         wave_mem_sync();
@@ -256,17 +307,16 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
         if (lane == 0) d.leaf_kind[b] = LEAF_NONE;
         return;
     }
-    const int pl = d.s_player[b];
-    Plane me = pl_load(d.board + (size_t)b * 8 + (pl == 1 ? 0 : 4));
-    Plane opp = pl_load(d.board + (size_t)b * 8 + (pl == 1 ? 4 : 0));
-    int row = 0, npar = rootN, depth = 0, last = d.s_last[b], out_kind = LEAF_NONE;
+    Plane me = pl == 1 ? bX : bO;
+    Plane opp = pl == 1 ? bO : bX;
+    int row = 0, npar = rootN, depth = 0, last = slast, out_kind = LEAF_NONE;
     for (;;) {
         Plane occ;
 #pragma unroll
         for (int q = 0; q < 4; q++) occ.w[q] = me.w[q] | opp.w[q];
-        const double sq = d.sqrt_table[npar];                 // np.sqrt(self.N + 1e-8), mcts.py:73
+        const double sq = sq_lds[npar];                       // np.sqrt(self.N + 1e-8), mcts.py:73
         double best = 0.0;
-        int bi = -1;
+        int bi = -1, bN = 0, bC = 0;
 #pragma unroll
         for (int i = 0; i < G::CPL; i++) {
             int j = lane + 64 * i;
@@ -274,13 +324,15 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
                 Edge e = rows[(size_t)row * G::RW + j];
                 double Q = e.N ? e.W / (double)e.N : 0.0;     // mcts.py:80 Q = W/N (0.0 while unvisited)
                 double sc = Q + ((d.c_puct * (double)e.P) * sq) / (double)(1 + (int)e.N);
-                if (bi < 0 || sc > best) { best = sc; bi = j; }
+                if (bi < 0 || sc > best) { best = sc; bi = j; bN = e.N; bC = e.child; }
             }
         }
         wave_argmax(best, bi);
         const int a = __builtin_amdgcn_readfirstlane(bi);
         if (a < 0) { out_kind = LEAF_NONE; break; }            // unreachable for a non-terminal root; never index with -1
-        Edge ea = rows[(size_t)row * G::RW + a];
+        // the lane that owns cell a (a & 63) holds its edge: the global best is also that lane's best
+        const int child = __shfl(bC, a & 63, 64);
+        const int an = __shfl(bN, a & 63, 64);
         if (lane == 0) path[depth] = ((unsigned)row << 16) | (unsigned)a;
         depth++;
         pl_set(me, a);                                        // games.py:79-81 place, flip player, remember action
@@ -288,9 +340,8 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
         last = a;
         if (wins_through(opp, a, N, d.k)) { out_kind = LEAF_TERM_LOSS; break; }  // the side to move has lost
         if (pl_count(me) + pl_count(opp) == G::nn) { out_kind = LEAF_TERM_DRAW; break; }
-        int child = __builtin_amdgcn_readfirstlane((int)ea.child);
         if (child == 0) { out_kind = LEAF_EXPAND; break; }    // mcts.py:127 node.is_leaf()
-        npar = __builtin_amdgcn_readfirstlane((int)ea.N);
+        npar = an;
         row = child;
     }
     if (lane == 0) {

@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--slots", type=int, default=1024, help="concurrent games per GPU")
     ap.add_argument("--no-episode", action="store_true", help="skip playing the episode to its end")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--pmc-run", action="store_true", help="counter-collection run: 8 sims per move so the pass stays short")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -86,7 +87,7 @@ def main():
     from alphazero_piskvorky_amd.weights import synthetic_state_dict
     from alphazero_piskvorky_amd import parallel
 
-    n, k, S, B = a.board, a.win, a.sims, a.slots
+    n, k, S, B = a.board, a.win, (8 if a.pmc_run else a.sims), a.slots
     sd = synthetic_state_dict(n)
     eng = az.Engine(n, k, S, B, device=local)
     eng.load_weights(sd, 0)
