@@ -9,4 +9,4 @@ include/az_engine.h.  The compute path is HIP only; nothing here falls back to t
     from alphazero_piskvorky_amd.controller import make_policy_value_fn, NeuralNetworkController
 """
 from . import _capi  # noqa: F401
-from ._capi import AzError, Engine  # noqa: F401
+from ._capi import AzError, Engine, MultiEngine  # noqa: F401

@@ -281,3 +281,84 @@ class Engine:
         c = az_counters()
         lib().az_get_counters(self.h, C.byref(c))
         return c.as_dict()
+
+
+class MultiEngine:
+    """K engines on one GPU, each with slots/K game slots and its own HIP stream, driven from K host threads.
+    Games are identified by id and seeded per id, so the episode is the same as with one engine; what changes is
+    that one engine's latency-bound tree/FC kernels run underneath another engine's conv trunk."""
+
+    def __init__(self, board_size, win_length, num_simulations, slots, engines=1, **kw):
+        from concurrent.futures import ThreadPoolExecutor
+        self.K = max(1, min(int(engines), slots))
+        per = (slots + self.K - 1) // self.K
+        self.parts = [Engine(board_size, win_length, num_simulations, min(per, slots - i * per), **kw) for i in range(self.K)]
+        self.n, self.nn, self.record_bytes = self.parts[0].n, self.parts[0].nn, self.parts[0].record_bytes
+        self.pool = ThreadPoolExecutor(self.K)
+        self.last_records = 0
+
+    def _all(self, fn):
+        return list(self.pool.map(fn, range(self.K)))
+
+    def load_weights(self, sd, slot=0):
+        for p in self.parts:
+            p.load_weights(sd, slot)
+
+    def selfplay_begin(self, num_games, seed0=0, max_plies=0, temperature_table=None):
+        per = (num_games + self.K - 1) // self.K
+        self.shares = [max(0, min(per, num_games - i * per)) for i in range(self.K)]
+        self._all(lambda i: self.parts[i].selfplay_begin(self.shares[i], seed0 + i * per, max_plies, temperature_table)
+                  if self.shares[i] else None)
+
+    @staticmethod
+    def _sum(cs):
+        out = dict(cs[0])
+        for c in cs[1:]:
+            for k, v in c.items():
+                out[k] = max(out[k], v) if k == "seconds" else out[k] + v
+        return out
+
+    def selfplay_step(self, max_steps=1):
+        res = self._all(lambda i: self.parts[i].selfplay_step(max_steps) if self.shares[i] else (0, None))
+        cs = [c for _, c in res if c is not None]
+        return sum(a for a, _ in res), self._sum(cs)
+
+    def selfplay_end(self):
+        cs = self._all(lambda i: self.parts[i].selfplay_end() if self.shares[i] else None)
+        cs = [c for c in cs if c is not None]
+        self.last_records = sum(int(c["records"]) for c in cs)
+        return self._sum(cs)
+
+    def selfplay(self, num_games, seed0=0, max_plies=0, temperature_table=None, **kw):
+        self.selfplay_begin(num_games, seed0, max_plies, temperature_table)
+        active = 1
+        while active > 0:
+            active, _ = self.selfplay_step(1 << 20)
+        return self.selfplay_end()
+
+    def step_one_engine(self, index=0, max_steps=1):
+        """Plays plies on ONE part while the others are idle (exclusive kernel timing for the roofline)."""
+        return self.parts[index].selfplay_step(max_steps)
+
+    def games(self):
+        outs = [p.games() for i, p in enumerate(self.parts) if self.shares[i]]
+        return np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs])
+
+    def records(self):
+        outs = [p.records() for i, p in enumerate(self.parts) if self.shares[i]]
+        return {k: np.concatenate([o[k] for o in outs]) for k in outs[0]}
+
+    def examples_from_packed(self, *a):
+        return self.parts[0].examples_from_packed(*a)
+
+    def pack_into(self, dev_ptr):
+        off = 0
+        for i, p in enumerate(self.parts):
+            if self.shares[i] and p.last_records:
+                p.pack_into(dev_ptr + off)
+                off += p.last_records * self.record_bytes
+
+    def close(self):
+        for p in self.parts:
+            p.close()
+        self.pool.shutdown(wait=False)

@@ -24,3 +24,4 @@ EVAL_TEMPERATURE = 0.3
 EVAL_TEMPERATURE_SCHEDULE_HALFTIME = 4
 # engine knobs (not in the reference)
 CONCURRENT_GAMES = 1024    # game slots per GPU
+ENGINES_PER_GPU = 4        # slots are split over this many engines/streams (tree + FC kernels overlap the conv trunk)

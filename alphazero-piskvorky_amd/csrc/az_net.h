@@ -22,7 +22,7 @@
 #define AZ_NW 8          // waves per trunk workgroup
 #endif
 #ifndef AZ_NTW
-#define AZ_NTW 2         // channel tiles per wave in the conv layers
+#define AZ_NTW 1         // channel tiles per wave in the conv layers (1: 15 cell tiles per wave, no surplus tile)
 #endif
 #ifndef AZ_SCHED
 #define AZ_SCHED 0       // 0: 1 MFMA : 1 LDS read interleave, 1: read burst then MFMA burst

@@ -37,9 +37,13 @@ def all_gather_packed(packed, count, record_bytes):
 def gather_packed_records(engine, device):
     """Pack this rank's episode records on the device and exchange them.  Returns (uint8 tensor of all records
     in rank order, per-rank counts)."""
+    import torch.distributed as td
     count = engine.last_records
     packed = torch.zeros(max(count, 1) * engine.record_bytes, dtype=torch.uint8, device=device)
     if count:
         engine.pack_into(packed.data_ptr())
-    parts, counts = all_gather_packed(packed, count, engine.record_bytes)
-    return torch.cat(parts) if len(parts) > 1 else parts[0], counts
+    # RCCL moves device buffers directly; with a gloo group (CPU tests, shared-GPU rehearsal) stage through the host
+    host_xchg = td.is_available() and td.is_initialized() and td.get_backend() != "nccl" and packed.device.type != "cpu"
+    parts, counts = all_gather_packed(packed.cpu() if host_xchg else packed, count, engine.record_bytes)
+    out = torch.cat(parts) if len(parts) > 1 else parts[0]
+    return (out.to(device) if host_xchg else out), counts

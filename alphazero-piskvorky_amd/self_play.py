@@ -7,7 +7,7 @@ import torch
 
 from . import constants as _c
 from . import parallel
-from ._capi import AZ_AUG_REFERENCE4, Engine
+from ._capi import AZ_AUG_REFERENCE4, MultiEngine
 from .controller import device_index
 from .mcts import numpy_log_table
 
@@ -20,7 +20,8 @@ def default_temperature_schedule(move: int) -> float:
 class SelfPlayManager:
     def __init__(self, controller, device, mcts_params: dict = None,
                  temperature_schedule: Callable[[int], float] = default_temperature_schedule,
-                 concurrent_games: int = None, augmentation: int = AZ_AUG_REFERENCE4, seed: int = None):
+                 concurrent_games: int = None, augmentation: int = AZ_AUG_REFERENCE4, seed: int = None,
+                 engines_per_gpu: int = None):
         self.controller = controller
         self.device = device
         self.mcts_params = mcts_params or {"num_simulations": 100}
@@ -28,6 +29,7 @@ class SelfPlayManager:
         self.concurrent_games = concurrent_games or _c.CONCURRENT_GAMES
         self.augmentation = augmentation      # 4 = the reference's rotations (self_play.py:94-108), 8 = full dihedral group, 1 = none
         self.seed = seed
+        self.engines_per_gpu = engines_per_gpu or _c.ENGINES_PER_GPU
         self.last_counters = None
         self._engine = None
 
@@ -38,8 +40,10 @@ class SelfPlayManager:
         if self._engine is None or self._engine_key != key:
             if self._engine is not None:
                 self._engine.close()
-            self._engine = Engine(n, k, key[2], slots, c_puct=key[4], dirichlet_alpha=key[5], dirichlet_weight=key[6],
-                                  device=device_index(self.device), log_table=numpy_log_table(key[2]))
+            engines = max(1, min(self.engines_per_gpu, slots // 128))     # small episodes are not worth splitting
+            self._engine = MultiEngine(n, k, key[2], slots, engines=engines, c_puct=key[4], dirichlet_alpha=key[5],
+                                       dirichlet_weight=key[6], device=device_index(self.device),
+                                       log_table=numpy_log_table(key[2]))
             self._engine_key = key
         return self._engine
 

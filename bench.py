@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--win", type=int, default=5)
     ap.add_argument("--sims", type=int, default=400)
     ap.add_argument("--slots", type=int, default=1024, help="concurrent games per GPU")
+    ap.add_argument("--engines", type=int, default=4, help="engines per GPU (slots are split; driven from host threads so that "
+                    "one engine's tree/FC kernels overlap another's conv trunk)")
     ap.add_argument("--no-episode", action="store_true", help="skip playing the episode to its end")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--pmc-run", action="store_true", help="counter-collection run: 8 sims per move so the pass stays short")
@@ -77,11 +79,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     dist = world > 1
+    ndev = torch.cuda.device_count()
+    share = dist and ndev < world          # rehearsal on a box with fewer GPUs than ranks: ranks share devices, gloo collectives
+    local = local % max(ndev, 1)
     if dist:
         import torch.distributed as td
         torch.cuda.set_device(local)
-        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if share:
+            td.init_process_group("gloo")
+        else:
+            td.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
+    cdev = torch.device("cpu") if share else dev      # where collective buffers live
 
     import alphazero_piskvorky_amd as az
     from alphazero_piskvorky_amd.weights import synthetic_state_dict
@@ -89,7 +98,7 @@ def main():
 
     n, k, S, B = a.board, a.win, (8 if a.pmc_run else a.sims), a.slots
     sd = synthetic_state_dict(n)
-    eng = az.Engine(n, k, S, B, device=local)
+    eng = az.MultiEngine(n, k, S, B, engines=a.engines, device=local)
     eng.load_weights(sd, 0)
     # every rank plays its own shard of the episode's games: ids rank*B .. rank*B+B-1 (seed = seed0 + id)
     eng.selfplay_begin(B, seed0=1_000_000 + rank * B)
@@ -102,6 +111,12 @@ def main():
 
     if a.warmup > 0:
         eng.selfplay_step(a.warmup)
+    # roofline calibration: ONE engine plays one ply while the others idle, so the HIP events around its trunk
+    # launches time the kernel alone on the GPU (with several engines the launches of different streams overlap)
+    barrier()
+    _, k0 = eng.step_one_engine(0, 0)
+    _, k1 = eng.step_one_engine(0, 1)
+    cal = {key: k1[key] - k0[key] for key in k1}
     barrier()
     _, c0 = eng.selfplay_step(0)
     t0 = time.perf_counter()
@@ -109,14 +124,14 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         dt = float(tmax.item())
 
     d = {key: c1[key] - c0[key] for key in c1}
     exp_local = d["expansions"] + (d["plies"])           # leaf expansions + root expansions (mcts.py:120,136-138)
     sums = torch.tensor([exp_local, d["simulations"], d["plies"], d["depth_sum"], d["terminal_hits"]],
-                        dtype=torch.float64, device=dev)
+                        dtype=torch.float64, device=cdev)
     if dist:
         td.all_reduce(sums, op=td.ReduceOp.SUM)
     exp_all, sims_all, plies_all, depth_all, term_all = [float(x) for x in sums.tolist()]
@@ -134,8 +149,8 @@ def main():
         packed, counts = parallel.gather_packed_records(eng, dev)
         torch.cuda.synchronize()
         tg = time.perf_counter() - tg0
-        ep = torch.tensor([ep_local, tg], dtype=torch.float64, device=dev)
-        tot = torch.tensor([cend["games"], cend["expansions"] + cend["plies"], cend["plies"]], dtype=torch.float64, device=dev)
+        ep = torch.tensor([ep_local, tg], dtype=torch.float64, device=cdev)
+        tot = torch.tensor([cend["games"], cend["expansions"] + cend["plies"], cend["plies"]], dtype=torch.float64, device=cdev)
         if dist:
             td.all_reduce(ep, op=td.ReduceOp.MAX)
             td.all_reduce(tot, op=td.ReduceOp.SUM)
@@ -149,18 +164,27 @@ def main():
 
     if rank == 0:
         trunk_f, fc_f = net_flops(n)
-        boards = d["expansions"] + d["plies"]            # boards the trunk kernel evaluated on this rank
-        launches = max(d["trunk_launches"], 1)
-        avg_ms = d["trunk_seconds"] * 1e3 / launches
+        boards = cal["expansions"] + cal["plies"]        # boards the trunk kernel evaluated in the calibration ply
+        launches = max(cal["trunk_launches"], 1)
+        avg_ms = cal["trunk_seconds"] * 1e3 / launches
         achieved = (boards / launches) * trunk_f / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         peak = 157.3
+        agg = (d["expansions"] + d["plies"]) * trunk_f / dt / 1e12   # trunk FLOPs of this rank per wall second, timed region
+        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as is)
+        traffic, traffic_src = None, None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))[f"k_trunk<{n}>"]
+            traffic = pm["hbm_bytes_per_board"] * boards / launches
+            traffic_src = "profiles/r01_pmc_summary.json (separate --pmc passes, per board x boards per launch)"
+        except Exception:
+            pass
         out = {
             "metric": "mcts_node_expansions_per_sec", "value": exp_all / dt, "unit": "node-expansions/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / max(a.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n}x{n} / {k}-in-a-row self-play, {B} concurrent games per GPU, {S} sims/move "
-                                   f"(BASELINE.json configs[3] per-GPU shard), GomokuNet random-init weights, numpy-compatible RNG tapes",
-                       "board": n, "win_length": k, "sims_per_move": S, "games_per_gpu": B, "parallelism": f"games sharded x{world}"},
+                                   f"{'(BASELINE.json configs[3] per-GPU shard)' if (n, k, S, B) == (15, 5, 400, 1024) else '(custom)'}, GomokuNet random-init weights, numpy-compatible RNG tapes",
+                       "board": n, "win_length": k, "sims_per_move": S, "games_per_gpu": B, "engines_per_gpu": a.engines, "parallelism": f"games sharded x{world}" + (" (ranks sharing GPUs, gloo rehearsal)" if share else "")},
             "per_gpu_node_expansions_per_sec": exp_all / dt / world,
             "simulations_per_sec": sims_all / dt, "plies_per_sec": plies_all / dt,
             "mean_select_depth": depth_all / max(sims_all, 1), "terminal_hit_fraction": term_all / max(sims_all, 1),
@@ -168,8 +192,13 @@ def main():
             "episode": episode,
             "roofline": {"kernel": f"k_trunk<{n}> (encode+conv1+conv2+conv3+head convs, LDS-resident, v_mfma_f32_16x16x4_f32)",
                          "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None, "avg_launch_ms": avg_ms, "boards_per_launch": boards / launches,
-                         "flops_per_board": trunk_f, "net_time_fraction": d["nn_seconds"] / max(d["seconds"], 1e-9)},
+                         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": avg_ms, "boards_per_launch": boards / launches,
+                         "flops_per_board": trunk_f,
+                         "measured": "HIP events around every k_trunk launch of one calibration ply played by a single engine "
+                                     "(other engines idle), between warmup and the timed region",
+                         "aggregate": {"achieved": agg, "frac": agg / peak, "unit": "TFLOP/s",
+                                       "what": "trunk FLOPs per wall second over the timed region, all engines/streams overlapping "
+                                               "(includes the time the FC and tree kernels take)"}},
         }
         if not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(n, k, S, sd, 0)

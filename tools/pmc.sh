@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 tag=$1; ctrs=$2
 mkdir -p gpurun_out/pmc
-rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d gpurun_out/pmc -o $tag -- python3 bench.py --steps 1 --warmup 0 --no-episode --no-cpu --pmc-run > gpurun_out/pmc/${tag}_run.log 2>&1
+rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d gpurun_out/pmc -o $tag -- python3 bench.py --steps 1 --warmup 0 --no-episode --no-cpu --pmc-run --engines 1 > gpurun_out/pmc/${tag}_run.log 2>&1
 python3 - <<PY
 import csv, collections
 rows = list(csv.DictReader(open("gpurun_out/pmc/${tag}_counter_collection.csv")))
