@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""The reference's training loop (train.py:39-131) on the GPU path: self-play -> replay buffer -> AdamW steps ->
+arena -> promote.  Everything expensive runs in the HIP engine; this file is glue and mirrors the reference's
+episode structure so that the drop-in can be exercised end to end:
+
+    python -m alphazero_piskvorky_amd.train --episodes 2 --games 64 --sims 50
+"""
+import argparse
+import copy
+import os
+import time
+
+import torch
+
+from . import constants as C
+from .controller import NeuralNetworkController
+from .evaluator import ModelEvaluator
+from .games import Gomoku
+from .net import GomokuNet
+from .replay_buffer import ReplayBuffer
+from .self_play import SelfPlayManager
+
+PROMOTION_THRESHOLD = 0.55          # promoter.py:19, strict ">" with draws counted one half
+
+
+def run(episodes, games, sims, eval_games, device="cuda:0", seed=0, model_dir=None, log=print):
+    torch.manual_seed(seed)
+    n = C.BOARD_SIZE
+    candidate = NeuralNetworkController(GomokuNet(board_size=n), device=device)
+    baseline = NeuralNetworkController(copy.deepcopy(candidate.net), device=device)
+    manager = SelfPlayManager(candidate, device, mcts_params={"num_simulations": sims, "c_puct": C.SELF_PLAY_EXPLORATION_CONSTANT},
+                              seed=seed)
+    evaluator = ModelEvaluator(game_class=Gomoku, print_games=False, device=device, seed=seed)
+    buffer = ReplayBuffer(capacity=C.BUFFER_CAPACITY)
+    history = []
+    saved_eval_sims = C.NUM_EVAL_SIMULATIONS
+    C.NUM_EVAL_SIMULATIONS = sims
+    try:
+        for ep in range(episodes):
+            t0 = time.perf_counter()
+            manager.seed = seed + 1_000_003 * ep
+            data = manager.generate_self_play(num_games=games, num_workers=C.NUM_WORKERS)       # train.py:89-92
+            buffer.extend(data)                                                                  # train.py:95
+            losses = []
+            for _ in range(C.BATCHES_PER_EPISODE):                                               # train.py:100-104
+                losses.append(candidate.train(buffer.sample_batch(C.BATCH_SIZE), epochs=C.NUM_EPOCHS))
+            evaluator.seed = seed + 7 * ep
+            win_rate, metrics = evaluator.evaluate(candidate, baseline, num_games=eval_games)    # promoter.py:38-43
+            promoted = win_rate > PROMOTION_THRESHOLD                                            # promoter.py:47
+            if promoted:
+                baseline.net.load_state_dict(candidate.net.state_dict())
+                if model_dir:
+                    os.makedirs(model_dir, exist_ok=True)
+                    candidate.save(os.path.join(model_dir, f"model_{int(time.time())}_{ep}.pt"))  # promoter.py:48-50
+            history.append(dict(episode=ep, examples=len(data), loss=losses[-1].get("loss"), win_rate=win_rate,
+                                promoted=promoted, seconds=time.perf_counter() - t0, **metrics))
+            log(f"[train] episode {ep}: {len(data)} examples, loss {losses[-1].get('loss'):.4f}, "
+                f"arena {metrics['wins']}/{metrics['losses']}/{metrics['draws']} -> {win_rate:.2%}"
+                f"{' (promoted)' if promoted else ''}, {history[-1]['seconds']:.1f}s")
+    finally:
+        C.NUM_EVAL_SIMULATIONS = saved_eval_sims
+    return history
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--episodes", type=int, default=C.NUM_EPISODES)
+    ap.add_argument("--games", type=int, default=C.NUM_SELF_PLAY_GAMES)
+    ap.add_argument("--sims", type=int, default=C.NUM_SELF_PLAY_SIMULATIONS)
+    ap.add_argument("--eval-games", type=int, default=C.EVALUATION_GAMES)
+    ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--model-dir", default=None)
+    a = ap.parse_args()
+    run(a.episodes, a.games, a.sims, a.eval_games, a.device, model_dir=a.model_dir)
+
+
+if __name__ == "__main__":
+    main()

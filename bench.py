@@ -42,7 +42,7 @@ def cpu_baseline(n, k, sims, sd, budget_games):
     o = orc.Oracle(n, k, sims)
     net = orc.Net(n, sd)
     plies = 2
-    games = max(cores, budget_games)
+    games = max(4 * cores, budget_games)     # about 10-30 s of CPU work on the box
     tapes = [orc.selfplay_tape(10_000 + g, n, maxply=plies) for g in range(games)]
 
     def one(g):
@@ -200,7 +200,7 @@ def main():
                                        "what": "trunk FLOPs per wall second over the timed region, all engines/streams overlapping "
                                                "(includes the time the FC and tree kernels take)"}},
         }
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:          # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(n, k, S, sd, 0)
         else:
             out["cpu_baseline"] = None

@@ -106,3 +106,18 @@ def test_model_evaluator_matches_reference_arena():
 def test_mcts_rejects_python_callables():
     with pytest.raises(NotImplementedError):
         MCTS(lambda s: (None, 0.0), num_simulations=10, c_puct=2.0)
+
+
+def test_training_loop_plumbing_config1():
+    """BASELINE.json configs[0] plumbing on the GPU path: self-play -> buffer -> AdamW -> arena -> promote (train.py:85-119)."""
+    from alphazero_piskvorky_amd import train
+    saved = (constants.BATCHES_PER_EPISODE, constants.NUM_EPOCHS, constants.BATCH_SIZE)
+    constants.BATCHES_PER_EPISODE, constants.NUM_EPOCHS, constants.BATCH_SIZE = 2, 1, 256
+    try:
+        hist = train.run(episodes=2, games=16, sims=24, eval_games=6, device="cuda:0", seed=3, log=lambda *_: None)
+    finally:
+        constants.BATCHES_PER_EPISODE, constants.NUM_EPOCHS, constants.BATCH_SIZE = saved
+    assert len(hist) == 2
+    for h in hist:
+        assert h["examples"] > 0 and h["examples"] % 4 == 0 and np.isfinite(h["loss"])
+        assert h["total"] == 6 and 0.0 <= h["win_rate"] <= 1.0 and h["wins"] + h["losses"] + h["draws"] == 6
