@@ -26,7 +26,7 @@ AZ_AUG_NONE, AZ_AUG_REFERENCE4, AZ_AUG_DIHEDRAL8 = 1, 4, 8
 EXPORTS = [
     "az_create", "az_destroy", "az_last_error", "az_load_weights", "az_net_eval", "az_search", "az_selfplay",
     "az_selfplay_begin", "az_selfplay_step", "az_selfplay_end", "az_selfplay_games", "az_selfplay_records", "az_record_bytes", "az_selfplay_pack", "az_examples_from_packed",
-    "az_arena", "az_rng_selfplay_tape", "az_rng_uniforms", "az_get_counters",
+    "az_examples_gather", "az_arena", "az_rng_selfplay_tape", "az_rng_uniforms", "az_get_counters",
 ]
 
 
@@ -264,6 +264,11 @@ class Engine:
         self._check(lib().az_examples_from_packed(self.h, C.c_void_p(packed_ptr), C.c_int64(records), int(aug),
                                                   C.c_void_p(states_ptr), C.c_void_p(pis_ptr), C.c_void_p(z_ptr)),
                     "az_examples_from_packed")
+
+    def examples_gather(self, packed_ptr, idx_ptr, sym_ptr, count, reference_pi, states_ptr, pis_ptr, z_ptr):
+        self._check(lib().az_examples_gather(self.h, C.c_void_p(packed_ptr), C.c_void_p(idx_ptr), C.c_void_p(sym_ptr),
+                                             int(count), int(reference_pi), C.c_void_p(states_ptr), C.c_void_p(pis_ptr),
+                                             C.c_void_p(z_ptr)), "az_examples_gather")
 
     # ---- arena ----
     def arena(self, num_games, seed0=0, temperature_table=None, u_tape=None):

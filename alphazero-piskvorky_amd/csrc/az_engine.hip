@@ -290,6 +290,34 @@ __global__ void k_examples(const unsigned char *packed, int64_t records, int n, 
     }
 }
 
+// Training batch straight from a device-resident ring of packed records: example i = symmetry sym[i] of record
+// idx[i] (replay_buffer.py:26-39 sample_batch + controller.py:23-31 collate, without the host round trip).
+__global__ void k_examples_gather(const unsigned char *packed, const long long *idx, const int *sym, int count, int n,
+                                  int64_t rb, int reference_pi, float *states, float *pis, float *zs)
+{
+    const int nn = n * n;
+    const int i = blockIdx.x;
+    if (i >= count) return;
+    const unsigned char *o = packed + idx[i] * rb;
+    const u64 *pl = reinterpret_cast<const u64 *>(o);
+    const float *pi = reinterpret_cast<const float *>(o + 64);
+    const int last = reinterpret_cast<const short *>(o + 64 + 4 * nn)[0];
+    const int z = reinterpret_cast<const signed char *>(o)[64 + 4 * nn + 3];
+    const int k = sym[i];
+    float *so = states + (size_t)i * 4 * nn;
+    float *po = pis + (size_t)i * nn;
+    for (int c = threadIdx.x; c < nn; c += blockDim.x) {
+        int r = c / n, q = c - r * n;
+        int src = sym_src(k, r, q, n);
+        so[c] = ((pl[src >> 6] >> (src & 63)) & 1ull) ? 1.0f : 0.0f;
+        so[nn + c] = ((pl[4 + (src >> 6)] >> (src & 63)) & 1ull) ? 1.0f : 0.0f;
+        so[2 * nn + c] = (src == last) ? 1.0f : 0.0f;
+        so[3 * nn + c] = 0.0f;
+        po[c] = pi[reference_pi ? sym_src(1, r, q, n) : src];
+    }
+    if (threadIdx.x == 0) zs[i] = (float)z;
+}
+
 // ------------------------------------------------------------------------------------------------
 // lifecycle
 // ------------------------------------------------------------------------------------------------
@@ -955,6 +983,21 @@ extern "C" int az_debug_stamps(az_engine *e, unsigned long long *out, int max_gr
     size_t n = std::min<size_t>((size_t)max_groups * 16, e->dbg.bytes / 8);
     if (max_groups < 0) n = e->dbg.bytes / 8;   // everything (trunk stamps, then k_fc stamps at offset B*16)
     HIPCHECK(e, hipMemcpy(out, e->dbg.p, n * 8, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+extern "C" int az_examples_gather(az_engine *e, const void *packed_dev, const int64_t *idx_dev, const int32_t *sym_dev,
+                                  int count, int reference_pi, float *states_dev, float *pis_dev, float *z_dev)
+{
+    if (!e || !packed_dev || !idx_dev || !sym_dev || !states_dev || !pis_dev || !z_dev || count < 0)
+        return fail(e, AZ_ERR_INVALID, "az_examples_gather: bad argument");
+    if (count == 0) return AZ_OK;
+    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    hipLaunchKernelGGL(k_examples_gather, dim3((unsigned)count), dim3(256), 0, e->stream, (const unsigned char *)packed_dev,
+                       (const long long *)idx_dev, (const int *)sym_dev, count, e->n, record_bytes(e->nn), reference_pi,
+                       states_dev, pis_dev, z_dev);
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    HIPCHECK(e, hipGetLastError());
     return AZ_OK;
 }
 

@@ -52,8 +52,8 @@ def run(episodes, games, sims, eval_games, device="cuda:0", seed=0, model_dir=No
                 if model_dir:
                     os.makedirs(model_dir, exist_ok=True)
                     candidate.save(os.path.join(model_dir, f"model_{int(time.time())}_{ep}.pt"))  # promoter.py:48-50
-            history.append(dict(episode=ep, examples=len(data), loss=losses[-1].get("loss"), win_rate=win_rate,
-                                promoted=promoted, seconds=time.perf_counter() - t0, **metrics))
+            history.append(dict(metrics, episode=ep, examples=len(data), loss=losses[-1].get("loss"),
+                                promoted=promoted, seconds=time.perf_counter() - t0))
             log(f"[train] episode {ep}: {len(data)} examples, loss {losses[-1].get('loss'):.4f}, "
                 f"arena {metrics['wins']}/{metrics['losses']}/{metrics['draws']} -> {win_rate:.2%}"
                 f"{' (promoted)' if promoted else ''}, {history[-1]['seconds']:.1f}s")

@@ -154,6 +154,13 @@ int az_selfplay_pack(az_engine *e, void *packed_dev);
 int az_examples_from_packed(az_engine *e, const void *packed_dev, int64_t records, int aug,
                             float *states_dev, float *pis_dev, float *z_dev);
 
+/* Training batch from a device-resident replay ring of packed records (replay_buffer.py:26-39 sample_batch +
+ * controller.py:23-31 collate, with no host round trip): example i = symmetry sym_dev[i] (0..7, dihedral group;
+ * 0..3 are the rotations) of record idx_dev[i].  reference_pi != 0 rotates pi once whatever the symmetry, like
+ * self_play.py:105 does.  All pointers are DEVICE pointers. */
+int az_examples_gather(az_engine *e, const void *packed_dev, const int64_t *idx_dev, const int32_t *sym_dev,
+                       int count, int reference_pi, float *states_dev, float *pis_dev, float *z_dev);
+
 /* ---- arena: ModelEvaluator.evaluate (evaluator.py:38-122) ----
  * candidate = slot 0 plays X, baseline = slot 1 plays O, odd game index => O moves first;
  * per-game RandomState(seed0 + g), one uniform per ply; temperature_table[step] =

@@ -121,3 +121,37 @@ def test_training_loop_plumbing_config1():
     for h in hist:
         assert h["examples"] > 0 and h["examples"] % 4 == 0 and np.isfinite(h["loss"])
         assert h["total"] == 6 and 0.0 <= h["win_rate"] <= 1.0 and h["wins"] + h["losses"] + h["draws"] == 6
+
+
+def test_device_replay_ring_matches_host_examples():
+    """sampling from the device ring gives exactly the examples generate_self_play would have produced."""
+    from alphazero_piskvorky_amd import Engine, parallel
+    from alphazero_piskvorky_amd.device_replay import DeviceReplayBuffer
+    n = 5
+    e = Engine(n, 4, 16, 8, synthetic=True)
+    c = e.selfplay(6, seed0=5)
+    R = c["records"]
+    dev = torch.device("cuda:0")
+    packed, counts = parallel.gather_packed_records(e, dev)
+    st = torch.empty((R * 4, 4, n, n), device=dev); pi = torch.empty((R * 4, n, n), device=dev); zz = torch.empty(R * 4, device=dev)
+    e.examples_from_packed(packed.data_ptr(), R, 4, st.data_ptr(), pi.data_ptr(), zz.data_ptr())
+    torch.cuda.synchronize()
+    buf = DeviceReplayBuffer(e, capacity=4 * R, device="cuda:0", seed=1)
+    buf.extend_packed(packed, R)
+    assert len(buf) == 4 * R
+    s, p, z = buf.sample_batch(4 * R)                       # without replacement: a permutation of all examples
+    torch.cuda.synchronize()
+    key = lambda a, b, c_: [(tuple(x.flatten().tolist()), tuple(y.flatten().tolist()), float(w)) for x, y, w in zip(a.cpu(), b.cpu(), c_.cpu())]
+    assert sorted(key(s, p, z)) == sorted(key(st, pi, zz))
+    # FIFO overwrite: a ring of half the size keeps only the newest positions
+    small = DeviceReplayBuffer(e, capacity=4 * (R // 2), device="cuda:0", seed=2)
+    small.extend_packed(packed, R)
+    s2, p2, z2 = small.sample_batch(10 ** 6)
+    keep = R // 2
+    assert s2.shape[0] == 4 * keep
+    assert sorted(key(s2, p2, z2)) == sorted(key(st[4 * (R - keep):], pi[4 * (R - keep):], zz[4 * (R - keep):]))
+    # feeds train_step directly (controller.py:100-131)
+    ctrl = _controller("ckpt_saved")
+    out = ctrl.train_step(s[:64], p[:64], z[:64])
+    assert np.isfinite(out["loss"])
+    e.close()
