@@ -1,0 +1,161 @@
+"""GPU edge cases and full-size invariants for the HIP engine (C-ABI), against the oracle or by size-independent properties."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc
+from tests.util import weights_from_fixture
+
+import alphazero_piskvorky_amd as az
+
+
+def _engine(n, k, S, slots=4, synthetic=False, **kw):
+    return az.Engine(n, k, S, slots, synthetic=synthetic, log_table=orc.numpy_log_table(S), **kw)
+
+
+def _random_position(rs, n, k, stones):
+    """Random non-terminal position reached by legal play (oracle rules)."""
+    o = orc.Oracle(n, k, 1)
+    while True:
+        acts = list(rs.permutation(n * n)[:stones])
+        rc, term, board, pl, res = o.replay(acts)
+        if rc == 0 and res == 0 and not term.any():
+            return board, pl, (acts[-1] if acts else -1)
+
+
+@pytest.mark.parametrize("T", [1e-8, 1e-7, 3e-7, 5.0])
+def test_temperature_extremes_match_oracle(T):
+    """T <= 1e-7 takes numpy's float32 path after the clip (mcts.py:156-157); large T flattens pi."""
+    n, k, S = 9, 5, 60
+    rs = np.random.RandomState(11)
+    e = _engine(n, k, S, synthetic=True)
+    o = orc.Oracle(n, k, S, synthetic=True)
+    for stones in (0, 7, 30):
+        board, pl, last = _random_position(rs, n, k, stones)
+        for u in (0.0, 0.37, 0.999999):
+            r = e.search(board, pl, last, T, None, u)
+            ro = o.search(None, board, pl, last, T, None, u)
+            assert np.array_equal(r["N"], ro["N"]) and r["action"] == ro["action"]
+            assert np.array_equal(r["pi"], ro["pi"])
+            assert abs(float(r["pi"].sum()) - 1.0) < 1e-5
+    e.close()
+
+
+def test_nearly_full_boards_terminal_leaves_and_draws():
+    """Searches near the end of 5x5 games walk into terminal leaves (wins and full-board draws, mcts.py:132-134)."""
+    n, k, S = 5, 4, 80
+    rs = np.random.RandomState(5)
+    e = _engine(n, k, S, synthetic=True)
+    o = orc.Oracle(n, k, S, synthetic=True)
+    seen = 0
+    for stones in (18, 20, 22, 23, 24):
+        for _ in range(4):
+            board, pl, last = _random_position(rs, n, k, stones)
+            A = n * n - stones
+            noise = rs.dirichlet([0.3] * A)
+            r = e.search(board, pl, last, 0.8, noise, 0.5)
+            ro = o.search(None, board, pl, last, 0.8, noise, 0.5)
+            assert np.array_equal(r["N"], ro["N"]) and np.array_equal(r["W"], ro["W"]) and r["action"] == ro["action"]
+            assert r["N"].sum() == S and (r["N"][board != 0] == 0).all()
+            seen += 1
+    assert seen == 20
+    e.close()
+
+
+@pytest.mark.parametrize("S,slots", [(1, 1), (2, 3), (1024, 2)])
+def test_simulation_count_and_slot_extremes(S, slots):
+    n, k = 5, 4
+    e = _engine(n, k, S, slots=slots, synthetic=True)
+    o = orc.Oracle(n, k, S, synthetic=True)
+    c = e.selfplay(3, seed0=21, max_plies=3)
+    rec = e.records(); nply, _ = e.games()
+    off = 0
+    for g in range(3):
+        noise, us = orc.selfplay_tape(21 + g, n)
+        r = o.selfplay_game(None, noise, us, maxply=3)
+        L = int(nply[g])
+        assert L == r["nply"]
+        assert np.array_equal(rec["visits"][off:off + L], r["visits"]) and np.array_equal(rec["actions"][off:off + L], r["actions"])
+        assert np.array_equal(rec["pis"][off:off + L], r["pis"])
+        off += L
+    assert c["simulations"] == S * c["plies"]
+    e.close()
+
+
+def test_invalid_arguments_are_rejected():
+    with pytest.raises(az.AzError):
+        az.Engine(5, 4, 2000, 4)                 # num_simulations > 1024
+    with pytest.raises(az.AzError):
+        az.Engine(5, 9, 10, 4)                   # win length > board
+    e = _engine(5, 4, 8, synthetic=True)
+    with pytest.raises(az.AzError):
+        e.search(np.zeros(25, np.uint8), 3, -1, 1.0)            # player must be 1 or 2
+    b = np.zeros(25, np.uint8); b[3] = 7
+    with pytest.raises(az.AzError):
+        e.search(b, 1, -1, 1.0)                                 # bad cell value
+    with pytest.raises(ValueError):
+        e.search(np.zeros(25, np.uint8), 1, -1, 1.0, noise=np.ones(3))   # noise length != legal cells
+    e.close()
+
+
+def _check_episode_invariants(n, k, S, rec, nply, res, games):
+    o = orc.Oracle(n, k, 1)
+    nn = n * n
+    assert rec["boards"].shape[0] == int(nply.sum())
+    assert (rec["visits"].sum(axis=1) == S).all()                              # every simulation passes one root child (Q7)
+    assert (rec["visits"][rec["boards"] != 0] == 0).all()                      # occupied cells are never selected
+    assert (rec["pis"][rec["boards"] != 0] == 0).all()
+    np.testing.assert_allclose(rec["pis"].sum(axis=1), 1.0, atol=2e-5)
+    chosen = rec["boards"][np.arange(len(rec["actions"])), rec["actions"]]
+    assert (chosen == 0).all()                                                 # moves are legal
+    off = 0
+    for g in range(games):
+        L = int(nply[g])
+        acts = rec["actions"][off:off + L]
+        rc, term, board, pl, result = o.replay(acts)                           # oracle rules replay
+        assert rc == 0 and not term.any()
+        assert result == int(res[g]) and result in (1, 2, 3)                   # finished, outcome identical
+        want = np.array([0 if result == 3 else (1 if m == result else -1) for m in rec["movers"][off:off + L]])
+        assert np.array_equal(rec["z"][off:off + L], want)
+        assert rec["movers"][off] == 1 and (np.diff(rec["movers"][off:off + L].astype(int)) != 0).all()
+        # the recorded board before ply m is the replay of the first m actions
+        for m in (0, L // 2, L - 1):
+            _, _, bm, _, _ = o.replay(acts[:m])
+            assert np.array_equal(rec["boards"][off + m], bm)
+        off += L
+
+
+def test_full_size_5x5_episode_with_refill_invariants():
+    """BASELINE configs[1] shape (5x5/4, 100 sims) with more games than slots: refill, outcomes, z, legality."""
+    n, k, S, G = 5, 4, 100, 1536
+    e = _engine(n, k, S, slots=1024)
+    e.load_weights(weights_from_fixture(n, "ckpt_saved"), 0)
+    c = e.selfplay(G, seed0=99)
+    rec = e.records(); nply, res = e.games()
+    assert c["games"] == G and c["plies"] == int(nply.sum()) and (nply > 0).all()
+    _check_episode_invariants(n, k, S, rec, nply, res, G)
+    e.close()
+
+
+def test_full_size_15x15_first_plies_invariants():
+    """BASELINE configs[3] per-GPU shard (15x15/5, 1024 games, 400 sims), first 3 plies: properties + oracle spot checks."""
+    n, k, S, G, cut = 15, 5, 400, 1024, 3
+    sd = weights_from_fixture(n, "seeded")
+    eng = az.MultiEngine(n, k, S, G, engines=4, log_table=orc.numpy_log_table(S))
+    eng.load_weights(sd, 0)
+    c = eng.selfplay(G, seed0=31337, max_plies=cut)
+    rec = eng.records(); nply, res = eng.games()
+    assert (nply == cut).all() and (res == 0).all() and c["plies"] == G * cut
+    assert (rec["visits"].sum(axis=1) == S).all()
+    assert (rec["visits"][rec["boards"] != 0] == 0).all()
+    np.testing.assert_allclose(rec["pis"].sum(axis=1), 1.0, atol=2e-5)
+    assert (rec["z"] == 99).all()                                               # cut games carry no label
+    o = orc.Oracle(n, k, S); onet = orc.Net(n, sd)
+    for g in (0, 255, 256, 777, 1023):                                          # spans all four engines
+        noise, us = orc.selfplay_tape(31337 + g, n, maxply=cut)
+        r = o.selfplay_game(onet, noise, us, maxply=cut)
+        sl = slice(g * cut, g * cut + cut)
+        assert np.array_equal(rec["actions"][sl], r["actions"]) and np.array_equal(rec["visits"][sl], r["visits"])
+        assert np.array_equal(rec["pis"][sl], r["pis"]) and np.array_equal(rec["boards"][sl], r["boards"])
+    eng.close()
