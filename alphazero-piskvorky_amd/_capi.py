@@ -22,9 +22,10 @@ STATE_DICT_ORDER = [
 AZ_EVAL_NET, AZ_EVAL_SYNTHETIC = 0, 1
 AZ_RES_NONE, AZ_RES_X, AZ_RES_O, AZ_RES_DRAW = 0, 1, 2, 3
 AZ_AUG_NONE, AZ_AUG_REFERENCE4, AZ_AUG_DIHEDRAL8 = 1, 4, 8
+AZ_MODEL_PLAIN, AZ_MODEL_RESNET = 0, 1
 
 EXPORTS = [
-    "az_create", "az_destroy", "az_last_error", "az_load_weights", "az_net_eval", "az_search", "az_selfplay",
+    "az_create", "az_destroy", "az_last_error", "az_load_weights", "az_load_weights_resnet", "az_net_eval", "az_search", "az_selfplay",
     "az_selfplay_begin", "az_selfplay_step", "az_selfplay_end", "az_selfplay_games", "az_selfplay_records", "az_record_bytes", "az_selfplay_pack", "az_examples_from_packed",
     "az_examples_gather", "az_arena", "az_rng_selfplay_tape", "az_rng_uniforms", "az_get_counters",
 ]
@@ -38,7 +39,7 @@ class az_config(C.Structure):
     _fields_ = [("board_size", C.c_int32), ("win_length", C.c_int32), ("num_simulations", C.c_int32),
                 ("slots", C.c_int32), ("c_puct", C.c_double), ("dirichlet_alpha", C.c_double),
                 ("dirichlet_weight", C.c_double), ("eval_kind", C.c_int32), ("device", C.c_int32),
-                ("log_table", C.POINTER(C.c_float))]
+                ("log_table", C.POINTER(C.c_float)), ("model", C.c_int32)]
 
 
 class az_selfplay_args(C.Structure):
@@ -141,15 +142,19 @@ class Engine:
     """One engine per GPU (az_create .. az_destroy)."""
 
     def __init__(self, board_size, win_length, num_simulations, slots, c_puct=2.0, dirichlet_alpha=0.3,
-                 dirichlet_weight=0.25, synthetic=False, device=0, log_table=None):
+                 dirichlet_weight=0.25, synthetic=False, device=0, log_table=None, model="plain"):
         self.n, self.k, self.S, self.slots = board_size, win_length, num_simulations, slots
+        if model not in ("plain", "resnet"):
+            raise ValueError("model must be 'plain' or 'resnet'")
+        self.model = model
         self.nn = board_size * board_size
         self._log_table = None if log_table is None else np.ascontiguousarray(log_table, np.float32)
         if self._log_table is not None and len(self._log_table) < num_simulations + 1:
             raise ValueError("log_table must have num_simulations + 1 entries")
         cfg = az_config(board_size, win_length, num_simulations, slots, c_puct, dirichlet_alpha, dirichlet_weight,
                         AZ_EVAL_SYNTHETIC if synthetic else AZ_EVAL_NET, device,
-                        None if self._log_table is None else self._log_table.ctypes.data_as(C.POINTER(C.c_float)))
+                        None if self._log_table is None else self._log_table.ctypes.data_as(C.POINTER(C.c_float)),
+                        AZ_MODEL_RESNET if model == "resnet" else AZ_MODEL_PLAIN)
         self.h = C.c_void_p()
         rc = lib().az_create(C.byref(cfg), C.byref(self.h))
         if rc:
@@ -174,6 +179,13 @@ class Engine:
 
     # ---- weights ----
     def load_weights(self, state_dict, slot=0):
+        if self.model == "resnet":
+            from .net import fold_resnet_state_dict
+            keep = state_dict if isinstance(state_dict, (list, tuple)) else fold_resnet_state_dict(state_dict)
+            keep = [np.ascontiguousarray(t, dtype=np.float32) for t in keep]
+            arr = (C.c_void_p * 24)(*[t.ctypes.data for t in keep])
+            self._check(lib().az_load_weights_resnet(self.h, int(slot), arr), "az_load_weights_resnet")
+            return
         keep = []
         for k in STATE_DICT_ORDER:
             t = state_dict[k]

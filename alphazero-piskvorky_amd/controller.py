@@ -21,7 +21,8 @@ class PolicyValueFn:
     def _eng(self, n):
         ver = weights_version(self.controller.net)
         if self._engine is None or self._engine.n != n:
-            self._engine = Engine(n, min(_c.WIN_LENGTH, n), 1, 1, device=device_index(self.controller.device))
+            self._engine = Engine(n, min(_c.WIN_LENGTH, n), 1, 1, device=device_index(self.controller.device),
+                                  model=model_kind(self.controller.net))
             self._version = None
         if ver != self._version:
             self._engine.load_weights(self.controller.net.state_dict(), 0)
@@ -38,6 +39,11 @@ class PolicyValueFn:
 
 def make_policy_value_fn(controller):
     return PolicyValueFn(controller)
+
+
+def model_kind(net):
+    from .net import GomokuResNet
+    return "resnet" if isinstance(net, GomokuResNet) else "plain"
 
 
 def device_index(device):
@@ -81,7 +87,7 @@ class NeuralNetworkController:
         self.optimizer.zero_grad()
         loss.backward()
         self.optimizer.step()
-        return {"loss": float(loss), "policy_loss": float(policy_loss), "value_loss": float(value_loss)}
+        return {"loss": loss.item(), "policy_loss": policy_loss.item(), "value_loss": value_loss.item()}
 
     def train(self, examples, epochs=1):
         n = self.net.board_size

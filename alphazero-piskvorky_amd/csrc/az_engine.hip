@@ -32,7 +32,9 @@ struct DevBuf {
 struct PackedNet {
     bool loaded = false;
     DevBuf c1, c2, c3, hd, pf, vf, c1b, c2b, c3b, hdb, pfb, vfb, v2w, v2b;
+    DevBuf rblk[6], rblkb[6];          // ResidualBlock variant: the six 64->64 convs (c1/c1b hold the stem)
     NetWeights w{};
+    ResWeights rw{};
 };
 
 struct az_engine {
@@ -132,14 +134,15 @@ static std::vector<float> pack_conv(const float *w, int cout, int cin)
             }
     return out;
 }
-static std::vector<float> pack_heads(const float *pw, const float *vw)
+static std::vector<float> pack_heads(const float *pw, int pc, const float *vw, int vc, int cin)
 {
-    // policy_conv [4][128], value_conv [2][128] -> one 16-column tile, 32 k-steps
-    std::vector<float> out((size_t)8 * 64 * 4, 0.0f);
-    for (int s = 0; s < 32; s++)
+    // policy_conv [pc][cin], value_conv [vc][cin] -> rows of one 16-row tile, cin/4 k-steps
+    const int ks = cin / 4;
+    std::vector<float> out((size_t)(ks / 4) * 64 * 4, 0.0f);
+    for (int s = 0; s < ks; s++)
         for (int lane = 0; lane < 64; lane++) {
             int ci = 4 * s + (lane >> 4), j = lane & 15;
-            float v = j < 4 ? pw[j * 128 + ci] : (j < 6 ? vw[(j - 4) * 128 + ci] : 0.0f);
+            float v = j < pc ? pw[j * cin + ci] : (j < pc + vc ? vw[(j - pc) * cin + ci] : 0.0f);
             out[(((size_t)s / 4) * 64 + lane) * 4 + (s % 4)] = v;
         }
     return out;
@@ -164,30 +167,37 @@ static std::vector<float> pack_fc(const float *w, int nout, int kin)
 // kernel dispatch by board size
 // ------------------------------------------------------------------------------------------------
 template <int N>
-static void launch_net(az_engine *e, int net_id)
-{
-    typedef NetGeo<N> G;
-    const int B = e->d.B;
-    dim3 gt((B + G::G - 1) / G::G), bt(AZ_NW * 64);
-    hipLaunchKernelGGL(k_trunk<N>, gt, bt, 0, e->stream, e->d, e->net[net_id].w, net_id, (float *)e->pol_feat.p, (unsigned long long *)e->dbg.p);
-    dim3 gf((B + 15) / 16, G::NSPLIT), bf(G::FCW * 64);
-    hipLaunchKernelGGL(k_fc<N>, gf, bf, 0, e->stream, e->d, e->net[net_id].w, net_id, (const float *)e->pol_feat.p,
-                       e->dbg.p ? (unsigned long long *)e->dbg.p + (size_t)e->d.B * 16 : nullptr);
-}
-template <int N>
 static void launch_trunk_only(az_engine *e, int net_id)
 {
-    typedef NetGeo<N> G;
-    dim3 gt((e->d.B + G::G - 1) / G::G), bt(AZ_NW * 64);
-    hipLaunchKernelGGL(k_trunk<N>, gt, bt, 0, e->stream, e->d, e->net[net_id].w, net_id, (float *)e->pol_feat.p, (unsigned long long *)e->dbg.p);
+    if (e->cfg.model == AZ_MODEL_RESNET) {
+        typedef ResGeo<N> G;
+        dim3 gt((e->d.B + G::G - 1) / G::G), bt(G::NW * 64);
+        hipLaunchKernelGGL(k_trunk_res<N>, gt, bt, 0, e->stream, e->d, e->net[net_id].rw, net_id, (float *)e->pol_feat.p);
+    } else {
+        typedef NetGeo<N> G;
+        dim3 gt((e->d.B + G::G - 1) / G::G), bt(G::NW * 64);
+        hipLaunchKernelGGL(k_trunk<N>, gt, bt, 0, e->stream, e->d, e->net[net_id].w, net_id, (float *)e->pol_feat.p, (unsigned long long *)e->dbg.p);
+    }
 }
 template <int N>
 static void launch_fc_only(az_engine *e, int net_id)
 {
-    typedef NetGeo<N> G;
-    dim3 gf((e->d.B + 15) / 16, G::NSPLIT), bf(G::FCW * 64);
-    hipLaunchKernelGGL(k_fc<N>, gf, bf, 0, e->stream, e->d, e->net[net_id].w, net_id, (const float *)e->pol_feat.p,
-                       e->dbg.p ? (unsigned long long *)e->dbg.p + (size_t)e->d.B * 16 : nullptr);
+    unsigned long long *dbgfc = e->dbg.p ? (unsigned long long *)e->dbg.p + (size_t)e->d.B * 16 : nullptr;
+    if (e->cfg.model == AZ_MODEL_RESNET) {
+        typedef ResGeo<N> G;
+        dim3 gf((e->d.B + 15) / 16, G::NSPLIT), bf(G::FCW * 64);
+        hipLaunchKernelGGL(k_fc<G>, gf, bf, 0, e->stream, e->d, e->net[net_id].w, net_id, (const float *)e->pol_feat.p, dbgfc);
+    } else {
+        typedef NetGeo<N> G;
+        dim3 gf((e->d.B + 15) / 16, G::NSPLIT), bf(G::FCW * 64);
+        hipLaunchKernelGGL(k_fc<G>, gf, bf, 0, e->stream, e->d, e->net[net_id].w, net_id, (const float *)e->pol_feat.p, dbgfc);
+    }
+}
+template <int N>
+static void launch_net(az_engine *e, int net_id)
+{
+    launch_trunk_only<N>(e, net_id);
+    launch_fc_only<N>(e, net_id);
 }
 template <int N>
 static void launch_step(az_engine *e, int rootN, int do_select)
@@ -350,6 +360,7 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
     if (cfg->win_length < 2 || cfg->win_length > cfg->board_size) return fail(nullptr, AZ_ERR_INVALID, "bad win_length");
     if (cfg->num_simulations < 1 || cfg->num_simulations > 1024) return fail(nullptr, AZ_ERR_INVALID, "num_simulations must be 1..1024");
     if (cfg->slots < 1 || cfg->slots > 65536) return fail(nullptr, AZ_ERR_INVALID, "slots must be 1..65536");
+    if (cfg->model != AZ_MODEL_PLAIN && cfg->model != AZ_MODEL_RESNET) return fail(nullptr, AZ_ERR_INVALID, "unknown model kind %d", cfg->model);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, AZ_ERR_NO_DEVICE, "no HIP device: this engine has no CPU fallback");
@@ -379,7 +390,7 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
     ALLOC(path, (B * (size_t)e->PATH + 64) * 4);   // +64: k_step's speculative path[lane] read of the last slot
     ALLOC(leaf_kind, B * 4); ALLOC(leaf, B * 8 * sizeof(u64)); ALLOC(leaf_last, B * 4);
     ALLOC(logits, B * (size_t)e->RW * 4); ALLOC(vhid, B * 64 * 4);
-    ALLOC(pol_feat, B * (size_t)(((6 * e->nn + 3) / 4) * 4) * 4);   // feature rows [B][FROW], zero tail stays zero
+    ALLOC(pol_feat, B * (size_t)((((cfg->model == AZ_MODEL_RESNET ? 3 : 6) * e->nn + 3) / 4) * 4) * 4);   // feature rows [B][FROW], zero tail stays zero
     ALLOC(cnt, B * 4 * sizeof(unsigned long long)); ALLOC(next_game, 16); ALLOC(active, 16); ALLOC(ticket, 16);
     ALLOC(T_table, (size_t)(e->nn + 4) * sizeof(double));
 #ifdef AZ_STAMPS
@@ -436,6 +447,7 @@ extern "C" void az_destroy(az_engine *e)
         PackedNet &p = e->net[s];
         DevBuf *nb[] = {&p.c1, &p.c2, &p.c3, &p.hd, &p.pf, &p.vf, &p.c1b, &p.c2b, &p.c3b, &p.hdb, &p.pfb, &p.vfb, &p.v2w, &p.v2b};
         for (DevBuf *b : nb) dev_free(*b);
+        for (int i = 0; i < 6; i++) { dev_free(p.rblk[i]); dev_free(p.rblkb[i]); }
     }
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -445,6 +457,7 @@ extern "C" void az_destroy(az_engine *e)
 extern "C" int az_load_weights(az_engine *e, int slot, const float *const *t)
 {
     if (!e || !t || slot < 0 || slot > 1) return fail(e, AZ_ERR_INVALID, "az_load_weights: bad argument");
+    if (e->cfg.model != AZ_MODEL_PLAIN) return fail(e, AZ_ERR_INVALID, "az_load_weights: engine was created for the ResidualBlock model");
     for (int i = 0; i < 16; i++)
         if (!t[i]) return fail(e, AZ_ERR_INVALID, "az_load_weights: tensor %d is null", i);
     HIPCHECK(e, hipSetDevice(e->cfg.device));
@@ -456,7 +469,7 @@ extern "C" int az_load_weights(az_engine *e, int slot, const float *const *t)
     up(p.c1, pack_conv(t[0], 32, 4));   upraw(p.c1b, t[1], 32);
     up(p.c2, pack_conv(t[2], 64, 32));  upraw(p.c2b, t[3], 64);
     up(p.c3, pack_conv(t[4], 128, 64)); upraw(p.c3b, t[5], 128);
-    up(p.hd, pack_heads(t[6], t[10]));
+    up(p.hd, pack_heads(t[6], 4, t[10], 2, 128));
     float hb[6] = {t[7][0], t[7][1], t[7][2], t[7][3], t[11][0], t[11][1]};
     upraw(p.hdb, hb, 6);
     up(p.pf, pack_fc(t[8], nn, 4 * nn));  upraw(p.pfb, t[9], nn);
@@ -467,6 +480,39 @@ extern "C" int az_load_weights(az_engine *e, int slot, const float *const *t)
     p.w.hd = (const float *)p.hd.p; p.w.pf = (const float *)p.pf.p; p.w.vf = (const float *)p.vf.p;
     p.w.c1b = (const float *)p.c1b.p; p.w.c2b = (const float *)p.c2b.p; p.w.c3b = (const float *)p.c3b.p;
     p.w.hdb = (const float *)p.hdb.p; p.w.pfb = (const float *)p.pfb.p; p.w.vfb = (const float *)p.vfb.p;
+    e->d.v2w[slot] = (const float *)p.v2w.p;
+    e->d.v2b[slot] = (const float *)p.v2b.p;
+    p.loaded = true;
+    return AZ_OK;
+}
+
+extern "C" int az_load_weights_resnet(az_engine *e, int slot, const float *const *t)
+{
+    if (!e || !t || slot < 0 || slot > 1) return fail(e, AZ_ERR_INVALID, "az_load_weights_resnet: bad argument");
+    if (e->cfg.model != AZ_MODEL_RESNET) return fail(e, AZ_ERR_INVALID, "az_load_weights_resnet: engine was created for the plain model");
+    for (int i = 0; i < 24; i++)
+        if (!t[i]) return fail(e, AZ_ERR_INVALID, "az_load_weights_resnet: tensor %d is null", i);
+    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    const int nn = e->nn;
+    PackedNet &p = e->net[slot];
+    int rc = AZ_OK;
+    auto up = [&](DevBuf &b, const std::vector<float> &v) { if (!rc) rc = upload(e, b, v.data(), v.size() * sizeof(float)); };
+    auto upraw = [&](DevBuf &b, const float *v, size_t cnt) { if (!rc) rc = upload(e, b, v, cnt * sizeof(float)); };
+    up(p.c1, pack_conv(t[0], 64, 4)); upraw(p.c1b, t[1], 64);
+    for (int i = 0; i < 6; i++) { up(p.rblk[i], pack_conv(t[2 + 2 * i], 64, 64)); upraw(p.rblkb[i], t[3 + 2 * i], 64); }
+    up(p.hd, pack_heads(t[14], 2, t[16], 1, 64));
+    float hb[3] = {t[15][0], t[15][1], t[17][0]};
+    upraw(p.hdb, hb, 3);
+    up(p.pf, pack_fc(t[18], nn, 2 * nn)); upraw(p.pfb, t[19], nn);
+    up(p.vf, pack_fc(t[20], 64, nn));     upraw(p.vfb, t[21], 64);
+    upraw(p.v2w, t[22], 64); upraw(p.v2b, t[23], 1);
+    if (rc) return rc;
+    p.rw.stem = (const float *)p.c1.p; p.rw.stemb = (const float *)p.c1b.p;
+    for (int i = 0; i < 6; i++) { p.rw.blk[i] = (const float *)p.rblk[i].p; p.rw.blkb[i] = (const float *)p.rblkb[i].p; }
+    p.rw.hd = (const float *)p.hd.p; p.rw.hdb = (const float *)p.hdb.p;
+    p.w = NetWeights{};
+    p.w.pf = (const float *)p.pf.p; p.w.vf = (const float *)p.vf.p;
+    p.w.pfb = (const float *)p.pfb.p; p.w.vfb = (const float *)p.vfb.p;
     e->d.v2w[slot] = (const float *)p.v2w.p;
     e->d.v2b[slot] = (const float *)p.v2b.p;
     p.loaded = true;

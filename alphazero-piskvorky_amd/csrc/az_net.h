@@ -49,18 +49,49 @@ struct NetGeo {
     static constexpr int CS3 = up16(MR);                           // channel stride of the conv3 output image
     static constexpr int LDSF = (96 * CS > 128 * CS3) ? 96 * CS : 128 * CS3;
     static constexpr int RW = ((nn + 63) / 64) * 64;
+    static constexpr int NW = AZ_NW;                               // waves per trunk workgroup
     // FC kernel
+    static constexpr int PC = 4, VC = 2;                           // policy_conv / value_conv output channels (net.py:46,52)
     static constexpr int NTP = (nn + 15) / 16;                     // policy N-tiles
-    static constexpr int KSP = nn;                                 // policy k-steps (4nn / 4)
-    static constexpr int KSV = (2 * nn + 3) / 4;                   // value_fc1 k-steps
-    static constexpr int FROW = ((6 * nn + 3) / 4) * 4;            // feature row in HBM: [0,4nn) policy, [4nn,6nn) value, zero tail
+    static constexpr int KSP = (PC * nn + 3) / 4;                  // policy k-steps
+    static constexpr int KSV = (VC * nn + 3) / 4;                  // value_fc1 k-steps
+    static constexpr int FROW = (((PC + VC) * nn + 3) / 4) * 4;    // feature row in HBM: [0,PC*nn) policy, [PC*nn,(PC+VC)*nn) value, zero tail
     static constexpr int KS4P_PAD = (((KSP + 3) / 4 + 15) / 16) * 16;   // policy weight groups padded to chunks of 16
     static constexpr int KS4V_PAD = (((KSV + 3) / 4 + 15) / 16) * 16;
-    static constexpr int FNEED = (KS4P_PAD * 16 > 4 * nn + KS4V_PAD * 16) ? KS4P_PAD * 16 : 4 * nn + KS4V_PAD * 16;
+    static constexpr int FNEED = (KS4P_PAD * 16 > PC * nn + KS4V_PAD * 16) ? KS4P_PAD * 16 : PC * nn + KS4V_PAD * 16;
     static constexpr int FSTR0 = FROW > FNEED ? FROW : FNEED;     // the padded k-steps read (zero) LDS beyond the row
     static constexpr int FSTR = FSTR0 + ((4 - (FSTR0 % 32) + 32) % 32);   // LDS row stride, == 4 (mod 32), multiple of 4
     static constexpr int FCW = 8;                                  // waves per k_fc workgroup (one 16x16 output tile each)
     static constexpr int NSPLIT = (NTP + 4 + FCW - 1) / FCW;       // workgroups per 16-board row: (B/16)*NSPLIT <= 256 -> one round
+};
+
+
+// Geometry of the ResidualBlock variant (BASELINE config 5; topology from the reference's historical checkpoints,
+// SURVEY.md §8c): 64-channel stem + 3 residual blocks, 2/1-channel heads.  Two 64-channel packed images live in LDS.
+template <int N>
+struct ResGeo {
+    static constexpr int n = N, nn = N * N, PW = N + 2, PP = PW * PW;
+    static constexpr int G = N == 15 ? 1 : (N == 9 ? 2 : 5);     // boards per workgroup (LDS: 2 x 64 channels)
+    static constexpr int M = G * nn;
+    static constexpr bool ROWT = (N == 15);
+    static constexpr int MT = ROWT ? G * N : (M + 15) / 16, MR = MT * 16;
+    static constexpr int CS = up16(G * PP);
+    static constexpr int CS3 = CS;                                 // unused (no conv3-style overlay)
+    static constexpr int LDSF = 128 * CS;
+    static constexpr int RW = ((nn + 63) / 64) * 64;
+    static constexpr int NW = N == 15 ? 12 : 8;                    // 4 channel tiles x {3,2} cell-tile groups: 15 = 3 x 5 tiles, no surplus
+    static constexpr int PC = 2, VC = 1;
+    static constexpr int NTP = (nn + 15) / 16;
+    static constexpr int KSP = (PC * nn + 3) / 4;
+    static constexpr int KSV = (VC * nn + 3) / 4;
+    static constexpr int FROW = (((PC + VC) * nn + 3) / 4) * 4;
+    static constexpr int KS4P_PAD = (((KSP + 3) / 4 + 15) / 16) * 16;
+    static constexpr int KS4V_PAD = (((KSV + 3) / 4 + 15) / 16) * 16;
+    static constexpr int FNEED = (KS4P_PAD * 16 > PC * nn + KS4V_PAD * 16) ? KS4P_PAD * 16 : PC * nn + KS4V_PAD * 16;
+    static constexpr int FSTR0 = FROW > FNEED ? FROW : FNEED;
+    static constexpr int FSTR = FSTR0 + ((4 - (FSTR0 % 32) + 32) % 32);
+    static constexpr int FCW = 8;
+    static constexpr int NSPLIT = (NTP + 4 + FCW - 1) / FCW;
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
@@ -72,11 +103,12 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
 //   float index  (((cg*4 + q) * CS + pos) * 4 + e)
 // so that ONE ds_read_b128 at (cg, q, pos) delivers the B-operand values of four consecutive k-steps
 // (e = 0..3) of lane group q, and the 16 lanes of a group read 256 contiguous bytes (conflict-free; CS % 16 == 0).
-template <int N>
+template <class GEO>
 __device__ __forceinline__ int pk_index(int ci, int pos)
 {
-    return ((((ci >> 4) * 4 + (ci & 3)) * NetGeo<N>::CS + pos) << 2) + ((ci >> 2) & 3);
+    return ((((ci >> 4) * 4 + (ci & 3)) * GEO::CS + pos) << 2) + ((ci >> 2) & 3);
 }
+enum { CONV_OUT_PACKED = 0, CONV_OUT3 = 1, CONV_OUT_RESIDUAL = 2 };   // RESIDUAL: relu(acc + bias + out[same index]) in place
 
 // One conv layer on the workgroup's LDS image, computed as D[co][cell] = sum_k W[co][k] * X[k][cell]:
 // the weight fragment is the MFMA A operand (row = output channel), the activation fragment the B operand
@@ -85,16 +117,16 @@ __device__ __forceinline__ int pk_index(int ci, int pos)
 // CIN == 4 (conv1) reads plain planes [ci][pos]; CIN >= 32 reads the packed image above.
 // OUT3=false: relu(acc+bias) -> packed image of the next layer.  OUT3=true (conv3): barrier, then the
 // [co][cell] image that overlays the (now dead) inputs.
-template <int N, int CIN, int COUT, bool OUT3>
+template <class G, int CIN, int COUT, int MODE>
 __device__ __forceinline__ void conv_layer(const float *in, float *out, const float *__restrict__ wp,
                                            const float *__restrict__ bias, const unsigned short *wpos,
                                            const unsigned short *cellof, int wave, int lane)
 {
-    typedef NetGeo<N> G;
+    constexpr bool OUT3 = MODE == CONV_OUT3;
     constexpr int NT = COUT / 16;                              // channel tiles
     constexpr int NTW = (AZ_NTW <= NT) ? AZ_NTW : NT;          // channel tiles per wave
     constexpr int NG = NT / NTW;                               // channel-tile groups
-    constexpr int MG = (AZ_NW / NG) > 0 ? (AZ_NW / NG) : 1;    // cell-tile groups
+    constexpr int MG = (G::NW / NG) > 0 ? (G::NW / NG) : 1;    // cell-tile groups
     constexpr int MTW = (G::MT + MG - 1) / MG;
     constexpr int KST = CIN / 4;           // k-steps per tap
     constexpr int KS = 9 * KST;
@@ -217,7 +249,13 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
                     float v = acc[t][i][rg] + bco[rg];
                     v = v > 0.0f ? v : 0.0f;
                     if constexpr (OUT3) out[co * G::CS3 + m] = v;
-                    else if (valid) out[pk_index<N>(co, pos)] = v;
+                    else if constexpr (MODE == CONV_OUT_RESIDUAL) {
+                        if (valid) {                          // net block: relu(bn2(conv2(h)) + x), x updated in place
+                            const int oi = pk_index<G>(co, pos);
+                            float r = acc[t][i][rg] + bco[rg] + out[oi];
+                            out[oi] = r > 0.0f ? r : 0.0f;
+                        }
+                    } else if (valid) out[pk_index<G>(co, pos)] = v;
                 }
             }
         }
@@ -294,17 +332,17 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk(DevState d, NetWeights w, 
     }
     __syncthreads();
     AZ_STAMP(1);
-    conv_layer<N, 4, 32, false>(inB, inA, w.c1, w.c1b, wpos, cellof, wave, lane);
+    conv_layer<G, 4, 32, CONV_OUT_PACKED>(inB, inA, w.c1, w.c1b, wpos, cellof, wave, lane);
     __syncthreads();
     // the input planes lived in the first 3 planes of inB; clear them before conv2's packed output lands there
     // (in packed coordinates some of those floats are padding-ring cells that conv2 never writes)
     for (int i = tid; i < 3 * G::CS; i += AZ_NW * 64) inB[i] = 0.0f;
     __syncthreads();
     AZ_STAMP(2);
-    conv_layer<N, 32, 64, false>(inA, inB, w.c2, w.c2b, wpos, cellof, wave, lane);
+    conv_layer<G, 32, 64, CONV_OUT_PACKED>(inA, inB, w.c2, w.c2b, wpos, cellof, wave, lane);
     __syncthreads();
     AZ_STAMP(3);
-    conv_layer<N, 64, 128, true>(inB, lds, w.c3, w.c3b, wpos, cellof, wave, lane);
+    conv_layer<G, 64, 128, CONV_OUT3>(inB, lds, w.c3, w.c3b, wpos, cellof, wave, lane);
     __syncthreads();
     AZ_STAMP(4);
     // policy_conv (128->4) and value_conv (128->2), 1x1: D[head channel][cell] over the conv3 image, 32 k-steps
@@ -357,12 +395,131 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk(DevState d, NetWeights w, 
     AZ_STAMP(5);
 }
 
-// policy_fc (net.py:65) and value_fc1 + ReLU (net.py:69) for 16 boards per workgroup row.
+// ------------------------------------------------------------------------------------------------
+// ResidualBlock variant: stem conv(4->64)+BN+ReLU, 3 x {conv+BN+ReLU, conv+BN, +skip, ReLU}, 1x1 heads (2 policy
+// channels, 1 value channel) + BN + ReLU.  Eval-mode BatchNorm is folded into the conv weights/biases by the host
+// layer.  Two 64-channel packed images in LDS: A holds the block input/output (updated in place by the skip add),
+// B the intermediate.
+// ------------------------------------------------------------------------------------------------
+struct ResWeights {
+    const float *stem, *stemb;
+    const float *blk[6], *blkb[6];     // res1.conv1, res1.conv2, res2.conv1, ... (MFMA-fragment packed), folded biases
+    const float *hd, *hdb;             // policy_conv (2) + value_conv (1) rows of one 16-row tile, folded biases [3]
+};
+
 template <int N>
-__global__ __launch_bounds__(NetGeo<N>::FCW * 64) void k_fc(DevState d, NetWeights w, int net_id, const float *__restrict__ feat,
-                                                            unsigned long long *dbgfc)
+__global__ __launch_bounds__(ResGeo<N>::NW * 64) void k_trunk_res(DevState d, ResWeights w, int net_id, float *__restrict__ feat)
 {
-    typedef NetGeo<N> G;
+    typedef ResGeo<N> G;
+    constexpr int NTH = G::NW * 64;
+    __shared__ __attribute__((aligned(16))) float lds[G::LDSF];
+    __shared__ unsigned short wpos[G::MR];
+    __shared__ unsigned short cellof[G::MR];
+    __shared__ int any_active;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b0 = blockIdx.x * G::G;
+    if (tid == 0) any_active = 0;
+    __syncthreads();
+    if (tid < G::G) {
+        int b = b0 + tid;
+        if (b < d.B) {
+            int kind = d.leaf_kind[b];
+            if ((kind == LEAF_ROOT || kind == LEAF_EXPAND) && d.s_status[b] == SLOT_ACTIVE && d.s_net[b] == net_id)
+                atomicOr(&any_active, 1);
+        }
+    }
+    __syncthreads();
+    if (!any_active) return;
+    float *A = lds, *B = lds + 64 * G::CS;
+    {
+        float4 *z = reinterpret_cast<float4 *>(lds);
+        for (int i = tid; i < G::LDSF / 4; i += NTH) z[i] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int m = tid; m < G::MR; m += NTH) {
+        int pos, cell;
+        if constexpr (G::ROWT) {
+            const int t = m >> 4, c = m & 15, g = t / N, r = t - g * N;
+            pos = g * G::PP + (r + 1) * G::PW + (c + 1);
+            cell = c < N ? g * G::nn + r * N + c : 0xFFFF;
+        } else {
+            const int g = m / G::nn, p = m - g * G::nn, r = p / N, c = p - r * N;
+            pos = m < G::M ? g * G::PP + (r + 1) * G::PW + (c + 1) : G::PW + 1;
+            cell = m < G::M ? m : 0xFFFF;
+        }
+        wpos[m] = (unsigned short)pos;
+        cellof[m] = (unsigned short)cell;
+    }
+    __syncthreads();
+    for (int m = tid; m < G::MR; m += NTH) {          // games.py:86-129 encode into plain planes at the start of B
+        const int cell = cellof[m];
+        if (cell != 0xFFFF) {
+            const int g = cell / G::nn, p = cell - g * G::nn;
+            const int b = b0 + g;
+            if (b < d.B) {
+                const u64 *lf = d.leaf + (size_t)b * 8;
+                const int pos = wpos[m];
+                if ((lf[p >> 6] >> (p & 63)) & 1ull) B[pos] = 1.0f;
+                if ((lf[4 + (p >> 6)] >> (p & 63)) & 1ull) B[G::CS + pos] = 1.0f;
+                if (d.leaf_last[b] == p) B[2 * G::CS + pos] = 1.0f;
+            }
+        }
+    }
+    __syncthreads();
+    conv_layer<G, 4, 64, CONV_OUT_PACKED>(B, A, w.stem, w.stemb, wpos, cellof, wave, lane);
+    __syncthreads();
+    for (int i = tid; i < 3 * G::CS; i += NTH) B[i] = 0.0f;     // the planes would alias padding cells of the packed image
+    __syncthreads();
+    for (int blk = 0; blk < 3; blk++) {
+        conv_layer<G, 64, 64, CONV_OUT_PACKED>(A, B, w.blk[2 * blk], w.blkb[2 * blk], wpos, cellof, wave, lane);
+        __syncthreads();
+        conv_layer<G, 64, 64, CONV_OUT_RESIDUAL>(B, A, w.blk[2 * blk + 1], w.blkb[2 * blk + 1], wpos, cellof, wave, lane);
+        __syncthreads();
+    }
+    // heads: D[head channel][cell] over the packed trunk image A, 16 k-steps (64 channels)
+    {
+        const int q = lane >> 4, r16 = lane & 15;
+        const float4 *wp4 = reinterpret_cast<const float4 *>(w.hd) + lane;
+        const float4 *in4 = reinterpret_cast<const float4 *>(A);
+        float hb[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) hb[rg] = (q * 4 + rg) < (G::PC + G::VC) ? w.hdb[q * 4 + rg] : 0.0f;
+        for (int mt = wave; mt < G::MT; mt += G::NW) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int base = q * G::CS + (int)wpos[mt * 16 + r16];
+#pragma unroll
+            for (int cg = 0; cg < 4; cg++) {
+                const float4 a = in4[base + cg * 4 * G::CS];
+                const float4 wq = wp4[cg * 64];
+                acc = mfma4(wq.x, a.x, acc);
+                acc = mfma4(wq.y, a.y, acc);
+                acc = mfma4(wq.z, a.z, acc);
+                acc = mfma4(wq.w, a.w, acc);
+            }
+            const int cell = cellof[mt * 16 + r16];
+            if (cell != 0xFFFF) {
+                const int g = cell / G::nn, p = cell - g * G::nn;
+                const int b = b0 + g;
+                if (b < d.B && d.s_net[b] == net_id) {
+#pragma unroll
+                    for (int rg = 0; rg < 4; rg++) {
+                        const int j = q * 4 + rg;     // 0-1 policy_conv, 2 value_conv
+                        if (j < G::PC + G::VC) {
+                            float v = acc[rg] + hb[rg];
+                            feat[(size_t)b * G::FROW + j * G::nn + p] = v > 0.0f ? v : 0.0f;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// policy_fc (net.py:65) and value_fc1 + ReLU (net.py:69) for 16 boards per workgroup row.
+template <class G>
+__global__ __launch_bounds__(G::FCW * 64) void k_fc(DevState d, NetWeights w, int net_id, const float *__restrict__ feat,
+                                                    unsigned long long *dbgfc)
+{
     __shared__ __attribute__((aligned(16))) float ft[16 * G::FSTR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mb = blockIdx.x * 16;
@@ -405,7 +562,7 @@ __global__ __launch_bounds__(NetGeo<N>::FCW * 64) void k_fc(DevState d, NetWeigh
     const int NCH = (KS4 + CH - 1) / CH;               // the packed weights are zero-padded to whole chunks of 16 groups
     const float4 *wp4 = reinterpret_cast<const float4 *>(is_pol ? w.pf : w.vf) +
                         (size_t)(is_pol ? tile : tile - G::NTP) * (is_pol ? G::KS4P_PAD : G::KS4V_PAD) * 64 + lane;
-    const float *ip = ft + r16 * G::FSTR + (is_pol ? 0 : 4 * G::nn) + q;
+    const float *ip = ft + r16 * G::FSTR + (is_pol ? 0 : G::PC * G::nn) + q;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     // One k-ordered MFMA chain.  Both operand streams are double-buffered a whole chunk (32 MFMAs) ahead: the
     // weight fragments come from L2, the feature fragments from LDS; the sched_barrier pins the loads above the chain.

@@ -5,7 +5,7 @@ import torch
 
 from . import constants as _c
 from ._capi import Engine
-from .controller import device_index
+from .controller import device_index, model_kind
 from .mcts import numpy_log_table
 
 
@@ -27,12 +27,12 @@ class ModelEvaluator:
         n = candidate_controller.net.board_size
         k = min(_c.WIN_LENGTH, n)
         S = _c.NUM_EVAL_SIMULATIONS
-        key = (n, k, S, num_games)
+        key = (n, k, S, num_games, model_kind(candidate_controller.net))
         if self._engine is None or self._key != key:
             if self._engine is not None:
                 self._engine.close()
             self._engine = Engine(n, k, S, max(1, min(num_games, _c.CONCURRENT_GAMES)), c_puct=_c.EVAL_EXPLORATION_CONSTANT,
-                                  device=device_index(self.device), log_table=numpy_log_table(S))
+                                  device=device_index(self.device), log_table=numpy_log_table(S), model=key[4])
             self._key = key
         eng = self._engine
         eng.load_weights(candidate_controller.net.state_dict(), 0)

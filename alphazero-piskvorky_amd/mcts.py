@@ -8,7 +8,7 @@ import numpy as np
 
 from . import constants as _c
 from ._capi import Engine
-from .controller import PolicyValueFn, device_index, weights_version
+from .controller import PolicyValueFn, device_index, model_kind, weights_version
 
 
 def numpy_log_table(S):
@@ -35,7 +35,8 @@ class MCTS:
         if self._engine is None or (self._engine.n, self._engine.k) != (n, k):
             self._engine = Engine(n, k, self.num_simulations, 1, c_puct=self.c_puct,
                                   dirichlet_alpha=self.dirichlet_alpha, dirichlet_weight=self.dirichlet_weight,
-                                  device=device_index(ctrl.device), log_table=numpy_log_table(self.num_simulations))
+                                  device=device_index(ctrl.device), log_table=numpy_log_table(self.num_simulations),
+                                  model=model_kind(ctrl.net))
             self._version = None
         ver = weights_version(ctrl.net)
         if ver != self._version:

@@ -8,7 +8,7 @@ import torch
 from . import constants as _c
 from . import parallel
 from ._capi import AZ_AUG_REFERENCE4, MultiEngine
-from .controller import device_index
+from .controller import device_index, model_kind
 from .mcts import numpy_log_table
 
 
@@ -36,14 +36,14 @@ class SelfPlayManager:
     def _eng(self, n, k, slots):
         p = self.mcts_params
         key = (n, k, p.get("num_simulations", 100), slots, p.get("c_puct", _c.SELF_PLAY_EXPLORATION_CONSTANT),
-               p.get("dirichlet_alpha", 0.3), p.get("dirichlet_weight", 0.25))
+               p.get("dirichlet_alpha", 0.3), p.get("dirichlet_weight", 0.25), model_kind(self.controller.net))
         if self._engine is None or self._engine_key != key:
             if self._engine is not None:
                 self._engine.close()
             engines = max(1, min(self.engines_per_gpu, slots // 128))     # small episodes are not worth splitting
             self._engine = MultiEngine(n, k, key[2], slots, engines=engines, c_puct=key[4], dirichlet_alpha=key[5],
                                        dirichlet_weight=key[6], device=device_index(self.device),
-                                       log_table=numpy_log_table(key[2]))
+                                       log_table=numpy_log_table(key[2]), model=key[7])
             self._engine_key = key
         return self._engine
 

@@ -25,9 +25,12 @@ import numpy as np
 import torch
 
 
-def net_flops(n):
-    """Algorithmic FLOPs (2*MAC) of one evaluation, SURVEY.md §8a a18: trunk (3 convs + 2 head convs) and FC tail."""
+def net_flops(n, model="plain"):
+    """Algorithmic FLOPs (2*MAC) of one evaluation: trunk (convs + head convs) and FC tail.
+    plain = SURVEY.md §8a a18; resnet = stem + 6 x (64->64) convs + 3 head channels (config 5)."""
     nn = n * n
+    if model == "resnet":
+        return 2 * nn * (36 * 64 + 6 * 576 * 64 + 64 * 3), 2 * (2 * nn * nn + nn * 64 + 64)
     trunk = 2 * nn * (36 * 32 + 288 * 64 + 576 * 128 + 128 * 6)
     fc = 2 * (4 * nn * nn + 2 * nn * 64 + 64)
     return trunk, fc
@@ -70,6 +73,7 @@ def main():
     ap.add_argument("--slots", type=int, default=1024, help="concurrent games per GPU")
     ap.add_argument("--engines", type=int, default=4, help="engines per GPU (slots are split; driven from host threads so that "
                     "one engine's tree/FC kernels overlap another's conv trunk)")
+    ap.add_argument("--model", default="plain", choices=["plain", "resnet"], help="plain = GomokuNet (net.py); resnet = ResidualBlock variant (config 5)")
     ap.add_argument("--no-episode", action="store_true", help="skip playing the episode to its end")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--pmc-run", action="store_true", help="counter-collection run: 8 sims per move so the pass stays short")
@@ -93,12 +97,12 @@ def main():
     cdev = torch.device("cpu") if share else dev      # where collective buffers live
 
     import alphazero_piskvorky_amd as az
-    from alphazero_piskvorky_amd.weights import synthetic_state_dict
+    from alphazero_piskvorky_amd.weights import synthetic_state_dict, synthetic_resnet_state_dict
     from alphazero_piskvorky_amd import parallel
 
     n, k, S, B = a.board, a.win, (8 if a.pmc_run else a.sims), a.slots
-    sd = synthetic_state_dict(n)
-    eng = az.MultiEngine(n, k, S, B, engines=a.engines, device=local)
+    sd = synthetic_resnet_state_dict(n) if a.model == "resnet" else synthetic_state_dict(n)
+    eng = az.MultiEngine(n, k, S, B, engines=a.engines, device=local, model=a.model)
     eng.load_weights(sd, 0)
     # every rank plays its own shard of the episode's games: ids rank*B .. rank*B+B-1 (seed = seed0 + id)
     eng.selfplay_begin(B, seed0=1_000_000 + rank * B)
@@ -163,7 +167,7 @@ def main():
         eng.selfplay_end()
 
     if rank == 0:
-        trunk_f, fc_f = net_flops(n)
+        trunk_f, fc_f = net_flops(n, a.model)
         boards = cal["expansions"] + cal["plies"]        # boards the trunk kernel evaluated in the calibration ply
         launches = max(cal["trunk_launches"], 1)
         avg_ms = cal["trunk_seconds"] * 1e3 / launches
@@ -173,6 +177,8 @@ def main():
         # HBM bytes per launch from the committed PMC passes (FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as is)
         traffic, traffic_src = None, None
         try:
+            if a.model != "plain":
+                raise KeyError("no PMC pass for this kernel yet")
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))[f"k_trunk<{n}>"]
             traffic = pm["hbm_bytes_per_board"] * boards / launches
             traffic_src = "profiles/r01_pmc_summary.json (separate --pmc passes, per board x boards per launch)"
@@ -183,14 +189,15 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / max(a.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n}x{n} / {k}-in-a-row self-play, {B} concurrent games per GPU, {S} sims/move "
-                                   f"{'(BASELINE.json configs[3] per-GPU shard)' if (n, k, S, B) == (15, 5, 400, 1024) else '(custom)'}, GomokuNet random-init weights, numpy-compatible RNG tapes",
+                                   f"{'(BASELINE.json configs[3] per-GPU shard)' if (n, k, S, B, a.model) == (15, 5, 400, 1024, 'plain') else '(custom)'}, {'GomokuNet' if a.model == 'plain' else 'ResidualBlock net'} random-init weights, numpy-compatible RNG tapes",
                        "board": n, "win_length": k, "sims_per_move": S, "games_per_gpu": B, "engines_per_gpu": a.engines, "parallelism": f"games sharded x{world}" + (" (ranks sharing GPUs, gloo rehearsal)" if share else "")},
             "per_gpu_node_expansions_per_sec": exp_all / dt / world,
             "simulations_per_sec": sims_all / dt, "plies_per_sec": plies_all / dt,
             "mean_select_depth": depth_all / max(sims_all, 1), "terminal_hit_fraction": term_all / max(sims_all, 1),
             "self_play_games_per_sec": None if episode is None else episode["games_per_sec"],
             "episode": episode,
-            "roofline": {"kernel": f"k_trunk<{n}> (encode+conv1+conv2+conv3+head convs, LDS-resident, v_mfma_f32_16x16x4_f32)",
+            "roofline": {"kernel": (f"k_trunk<{n}> (encode+conv1+conv2+conv3+head convs, LDS-resident, v_mfma_f32_16x16x4_f32)" if a.model == "plain"
+                                    else f"k_trunk_res<{n}> (encode+stem+3 residual blocks+head convs, LDS-resident, v_mfma_f32_16x16x4_f32)"),
                          "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": avg_ms, "boards_per_launch": boards / launches,
                          "flops_per_board": trunk_f,
@@ -200,7 +207,7 @@ def main():
                                        "what": "trunk FLOPs per wall second over the timed region, all engines/streams overlapping "
                                                "(includes the time the FC and tree kernels take)"}},
         }
-        if not a.no_cpu and world == 1:          # reported at N = 1 only
+        if not a.no_cpu and world == 1 and a.model == "plain":          # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(n, k, S, sd, 0)
         else:
             out["cpu_baseline"] = None

@@ -42,6 +42,7 @@ typedef enum {
 enum { AZ_EVAL_NET = 0, AZ_EVAL_SYNTHETIC = 1 };   /* synthetic = deterministic hash evaluator (test hook, mcts.py:87-93 seam) */
 enum { AZ_RES_NONE = 0, AZ_RES_X = 1, AZ_RES_O = 2, AZ_RES_DRAW = 3 }; /* constants.py:11-13 'X','O','D' */
 enum { AZ_AUG_REFERENCE4 = 4, AZ_AUG_DIHEDRAL8 = 8, AZ_AUG_NONE = 1 };
+enum { AZ_MODEL_PLAIN = 0, AZ_MODEL_RESNET = 1 };  /* net.py GomokuNet | ResidualBlock variant (README.md:72) */
 
 /* Hyper-parameters the reference keeps in constants.py / MCTS.__init__ (mcts.py:87-97). */
 typedef struct {
@@ -58,6 +59,7 @@ typedef struct {
        log_table[N] = float32 log(N + 1e-8) for N = 0..num_simulations (mcts.py:161);
        NULL -> computed with libm logf.                                                          */
     const float *log_table;
+    int32_t model;             /* AZ_MODEL_PLAIN (net.py:16-72) | AZ_MODEL_RESNET (config 5)                         */
 } az_config;
 
 /* ---- lifecycle ---- */
@@ -70,6 +72,16 @@ const char *az_last_error(const az_engine *e);   /* valid until the next call on
  * policy_conv.*, policy_fc.*, value_conv.*, value_fc1.*, value_fc2.*), fp32, torch layouts.
  * slot 0 = self-play / candidate, slot 1 = arena baseline (evaluator.py:53-62). */
 int az_load_weights(az_engine *e, int slot, const float *const *tensors);
+
+/* ResidualBlock variant (engines created with model = AZ_MODEL_RESNET).  The reference no longer ships a forward
+ * for it; the topology is fixed by its historical checkpoints (alphazero/models/old/model_20250728_*.pt) and the
+ * block by legacy/resnet/example.py:9-27: conv(4->64)+BN+ReLU, 3 x {conv+BN+ReLU, conv+BN, +skip, ReLU},
+ * policy_conv(64->2)+BN+ReLU -> policy_fc(2n^2 -> n^2), value_conv(64->1)+BN+ReLU -> value_fc1(n^2 -> 64) -> ReLU ->
+ * value_fc2 -> tanh.  tensors[24], fp32, eval-mode BatchNorm already FOLDED into conv weight/bias by the caller:
+ *   0,1 stem w[64,4,3,3], b[64];  2+2i, 3+2i (i = 0..5) res{1,2,3}.conv{1,2} w[64,64,3,3], b[64];
+ *   14,15 policy_conv w[2,64], b[2];  16,17 value_conv w[1,64], b[1];  18,19 policy_fc w[n^2,2n^2], b[n^2];
+ *   20,21 value_fc1 w[64,n^2], b[64];  22,23 value_fc2 w[64], b[1]. */
+int az_load_weights_resnet(az_engine *e, int slot, const float *const *tensors);
 
 /* ---- batched net evaluation: controller.make_policy_value_fn (controller.py:33-55) ----
  * boards[count][n*n] absolute cells (0 empty, 1 X, 2 O), players[count] side to move,

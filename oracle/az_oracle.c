@@ -216,6 +216,8 @@ int orc_result(int n, int k, const uint8_t *board)
 /* ------------------------------------------------------------------ net (net.py / controller.py) */
 typedef struct {
     int n;
+    int kind;                       /* 0 = GomokuNet (net.py), 1 = ResidualBlock variant (forward defined by the build) */
+    float *rw[7], *rb[7];           /* kind 1: stem + six 64->64 convs, BN folded by the caller, repacked [tap][ci][co] */
     /* repacked for the canonical k order: conv w[tap][ci][co] */
     float *c1w, *c1b, *c2w, *c2b, *c3w, *c3b;
     float *pcw, *pcb, *pfw, *pfb;   /* policy_conv [4][128], policy_fc [nn][4nn] */
@@ -258,17 +260,40 @@ orc_net *orc_net_create(int n, const float *const *t)
     return N;
 }
 
+/* ResidualBlock variant, tensors[24] exactly as include/az_engine.h az_load_weights_resnet documents (BN folded). */
+orc_net *orc_resnet_create(int n, const float *const *t)
+{
+    int nn = n * n;
+    orc_net *N = (orc_net *)calloc(1, sizeof *N);
+    N->n = n; N->kind = 1;
+    N->rw[0] = repack_conv(t[0], 64, 4); N->rb[0] = dupf(t[1], 64);
+    for (int i = 0; i < 6; i++) { N->rw[1 + i] = repack_conv(t[2 + 2 * i], 64, 64); N->rb[1 + i] = dupf(t[3 + 2 * i], 64); }
+    N->pcw = dupf(t[14], 2 * 64); N->pcb = dupf(t[15], 2);
+    N->vcw = dupf(t[16], 64);     N->vcb = dupf(t[17], 1);
+    N->pfw = dupf(t[18], (size_t)nn * 2 * nn); N->pfb = dupf(t[19], nn);
+    N->v1w = dupf(t[20], (size_t)64 * nn);     N->v1b = dupf(t[21], 64);
+    N->v2w = dupf(t[22], 64); N->v2b = dupf(t[23], 1);
+    return N;
+}
+
 void orc_net_free(orc_net *N)
 {
     if (!N) return;
+    for (int i = 0; i < 7; i++) { free(N->rw[i]); free(N->rb[i]); }
     free(N->c1w); free(N->c1b); free(N->c2w); free(N->c2b); free(N->c3w); free(N->c3b);
     free(N->pcw); free(N->pcb); free(N->pfw); free(N->pfb);
     free(N->vcw); free(N->vcb); free(N->v1w); free(N->v1b); free(N->v2w); free(N->v2b);
     free(N);
 }
 
+static void conv3x3_core(int n, int cin, int cout, const float *in, const float *w, const float *b, float *out, int residual);
 /* 3x3 same-padding conv + bias + ReLU, canonical chain; in [cin][nn], out [cout][nn] */
 static void conv3x3_relu(int n, int cin, int cout, const float *in, const float *w, const float *b, float *out)
+{
+    conv3x3_core(n, cin, cout, in, w, b, out, 0);
+}
+/* residual != 0: out = relu((acc + bias) + out), the skip connection of a ResidualBlock updated in place */
+static void conv3x3_core(int n, int cin, int cout, const float *in, const float *w, const float *b, float *out, int residual)
 {
     int nn = n * n;
     float acc[128];
@@ -286,6 +311,7 @@ static void conv3x3_relu(int n, int cin, int cout, const float *in, const float 
             }
             for (int co = 0; co < cout; co++) {
                 float v = acc[co] + b[co];
+                if (residual) v = v + out[co * nn + r * n + c];
                 out[co * nn + r * n + c] = v > 0.0f ? v : 0.0f;
             }
         }
@@ -297,6 +323,45 @@ static void net_forward(const orc_net *N, const float *planes, float *logits, fl
     int n = N->n, nn = n * n;
     static __thread float a1[32 * ORC_MAXNN], a2[64 * ORC_MAXNN], a3[128 * ORC_MAXNN];
     static __thread float pf[4 * ORC_MAXNN], vf[2 * ORC_MAXNN];
+    if (N->kind == 1) {
+        /* stem, then 3 x { h = relu(conv1(x)); x = relu(conv2(h) + x) } with BN folded (legacy/resnet/example.py:9-27) */
+        float *x = a2, *h = a3;
+        conv3x3_relu(n, 4, 64, planes, N->rw[0], N->rb[0], x);
+        for (int blk = 0; blk < 3; blk++) {
+            conv3x3_core(n, 64, 64, x, N->rw[1 + 2 * blk], N->rb[1 + 2 * blk], h, 0);
+            conv3x3_core(n, 64, 64, h, N->rw[2 + 2 * blk], N->rb[2 + 2 * blk], x, 1);
+        }
+        for (int pos = 0; pos < nn; pos++) {
+            for (int c = 0; c < 2; c++) {
+                float acc = 0.0f;
+                for (int ci = 0; ci < 64; ci++) acc = fmaf(x[ci * nn + pos], N->pcw[c * 64 + ci], acc);
+                float v = acc + N->pcb[c];
+                pf[c * nn + pos] = v > 0.0f ? v : 0.0f;
+            }
+            float acc = 0.0f;
+            for (int ci = 0; ci < 64; ci++) acc = fmaf(x[ci * nn + pos], N->vcw[ci], acc);
+            float v = acc + N->vcb[0];
+            vf[pos] = v > 0.0f ? v : 0.0f;
+        }
+        for (int j = 0; j < nn; j++) {
+            float acc = 0.0f;
+            const float *wr = N->pfw + (size_t)j * 2 * nn;
+            for (int q = 0; q < 2 * nn; q++) acc = fmaf(pf[q], wr[q], acc);
+            logits[j] = acc + N->pfb[j];
+        }
+        float hh[64];
+        for (int i = 0; i < 64; i++) {
+            float acc = 0.0f;
+            const float *wr = N->v1w + (size_t)i * nn;
+            for (int q = 0; q < nn; q++) acc = fmaf(vf[q], wr[q], acc);
+            float v = acc + N->v1b[i];
+            hh[i] = v > 0.0f ? v : 0.0f;
+        }
+        float acc = 0.0f;
+        for (int i = 0; i < 64; i++) acc = fmaf(hh[i], N->v2w[i], acc);
+        *value = orc_tanhf(acc + N->v2b[0]);
+        return;
+    }
     conv3x3_relu(n, 4, 32, planes, N->c1w, N->c1b, a1);
     conv3x3_relu(n, 32, 64, a1, N->c2w, N->c2b, a2);
     conv3x3_relu(n, 64, 128, a2, N->c3w, N->c3b, a3);

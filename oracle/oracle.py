@@ -41,6 +41,8 @@ def lib():
         L = _LIB
         L.orc_net_create.restype = C.c_void_p
         L.orc_net_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.orc_resnet_create.restype = C.c_void_p
+        L.orc_resnet_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.orc_net_free.argtypes = [C.c_void_p]
         L.orc_net_eval.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.orc_search.restype = C.c_int
@@ -84,8 +86,15 @@ def selfplay_tape(seed, n, maxply=None):
 
 
 class Net:
-    def __init__(self, n, sd):
+    def __init__(self, n, sd=None, resnet_tensors=None):
+        """sd: GomokuNet state_dict (numpy); resnet_tensors: the 24 folded tensors of az_load_weights_resnet."""
         self.n = n
+        if resnet_tensors is not None:
+            self._keep = [np.ascontiguousarray(np.asarray(t, dtype=np.float32)) for t in resnet_tensors]
+            assert len(self._keep) == 24
+            arr = (C.c_void_p * 24)(*[t.ctypes.data for t in self._keep])
+            self.h = lib().orc_resnet_create(n, arr)
+            return
         self._keep = [np.ascontiguousarray(np.asarray(sd[k], dtype=np.float32)) for k in STATE_DICT_ORDER]
         arr = (C.c_void_p * 16)(*[t.ctypes.data for t in self._keep])
         self.h = lib().orc_net_create(n, arr)
