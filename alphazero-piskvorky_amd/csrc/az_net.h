@@ -531,6 +531,22 @@ __global__ __launch_bounds__(G::FCW * 64) void k_fc(DevState d, NetWeights w, in
 #define FC_STAMP(k) do { } while (0)
 #endif
     FC_STAMP(0);
+    // nothing to do for a row of 16 boards without a pending evaluation (episode tails, terminal leaves)
+    {
+        __shared__ int fc_active;
+        if (tid == 0) fc_active = 0;
+        __syncthreads();
+        if (tid < 16) {
+            const int b = mb + tid;
+            if (b < d.B) {
+                const int kind = d.leaf_kind[b];
+                if ((kind == LEAF_ROOT || kind == LEAF_EXPAND) && d.s_status[b] == SLOT_ACTIVE && d.s_net[b] == net_id)
+                    atomicOr(&fc_active, 1);
+            }
+        }
+        __syncthreads();
+        if (!fc_active) return;
+    }
     // the LDS tail [FROW, FSTR) is zeroed: the padded k-steps of the last weight group read it (times zero weights)
     constexpr int V = G::FROW / 4, VS = G::FSTR / 4;
     static_assert(G::FNEED <= G::FSTR, "feature tile too narrow");
