@@ -39,7 +39,7 @@ __host__ __device__ constexpr int up16(int x) { return x + ((16 - (x % 32) + 32)
 template <int N>
 struct NetGeo {
     static constexpr int n = N, nn = N * N, PW = N + 2, PP = PW * PW;
-    static constexpr int G = N == 15 ? 1 : (N == 9 ? 3 : 7);     // boards per workgroup
+    static constexpr int G = N == 15 ? 1 : (N == 9 ? 3 : 4);     // boards per workgroup (5x5: 4 -> 256 workgroups at 1024 games, 2 per CU)
     static constexpr int M = G * nn;                               // real GEMM columns (board cells)
     // 16-cell MFMA tiles.  n = 15: one tile = one board row + its right padding cell (contiguous in the padded
     // image, so the 16 lanes of a fragment hit 16 consecutive LDS banks); other sizes: 16 consecutive cells.
@@ -71,7 +71,7 @@ struct NetGeo {
 template <int N>
 struct ResGeo {
     static constexpr int n = N, nn = N * N, PW = N + 2, PP = PW * PW;
-    static constexpr int G = N == 15 ? 1 : (N == 9 ? 2 : 5);     // boards per workgroup (LDS: 2 x 64 channels)
+    static constexpr int G = N == 15 ? 1 : (N == 9 ? 2 : 4);     // boards per workgroup (LDS: 2 x 64 channels)
     static constexpr int M = G * nn;
     static constexpr bool ROWT = (N == 15);
     static constexpr int MT = ROWT ? G * N : (M + 15) / 16, MR = MT * 16;
