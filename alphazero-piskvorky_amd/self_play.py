@@ -40,7 +40,8 @@ class SelfPlayManager:
         if self._engine is None or self._engine_key != key:
             if self._engine is not None:
                 self._engine.close()
-            engines = max(1, min(self.engines_per_gpu, slots // 128))     # small episodes are not worth splitting
+            # small boards are launch-bound (one engine), small episodes are not worth splitting
+            engines = 1 if n <= 5 else max(1, min(self.engines_per_gpu, slots // 128))
             self._engine = MultiEngine(n, k, key[2], slots, engines=engines, c_puct=key[4], dirichlet_alpha=key[5],
                                        dirichlet_weight=key[6], device=device_index(self.device),
                                        log_table=numpy_log_table(key[2]), model=key[7])

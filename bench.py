@@ -71,8 +71,8 @@ def main():
     ap.add_argument("--win", type=int, default=5)
     ap.add_argument("--sims", type=int, default=400)
     ap.add_argument("--slots", type=int, default=1024, help="concurrent games per GPU")
-    ap.add_argument("--engines", type=int, default=4, help="engines per GPU (slots are split; driven from host threads so that "
-                    "one engine's tree/FC kernels overlap another's conv trunk)")
+    ap.add_argument("--engines", type=int, default=0, help="engines per GPU (slots are split; driven from host threads so that "
+                    "one engine's tree/FC kernels overlap another's conv trunk); 0 = auto: 1 for 5x5 (launch-bound), 4 otherwise")
     ap.add_argument("--model", default="plain", choices=["plain", "resnet"], help="plain = GomokuNet (net.py); resnet = ResidualBlock variant (config 5)")
     ap.add_argument("--no-episode", action="store_true", help="skip playing the episode to its end")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -101,6 +101,8 @@ def main():
     from alphazero_piskvorky_amd import parallel
 
     n, k, S, B = a.board, a.win, (8 if a.pmc_run else a.sims), a.slots
+    if a.engines <= 0:
+        a.engines = 1 if n <= 5 else 4
     sd = synthetic_resnet_state_dict(n) if a.model == "resnet" else synthetic_state_dict(n)
     eng = az.MultiEngine(n, k, S, B, engines=a.engines, device=local, model=a.model)
     eng.load_weights(sd, 0)
