@@ -43,14 +43,13 @@ struct az_engine {
     std::string err;
     hipStream_t stream = nullptr;
     DevState d{};
-    std::vector<DevBuf *> owned;
     // per-engine buffers
     DevBuf board, s_game, s_ply, s_player, s_last, s_status, s_net, edges, rows_used, path, depth, leaf_kind, leaf,
-        leaf_last, logits, vhid, pol_feat, val_feat, T_table, log_table, sqrt_table, noise_off, cnt, next_game, active, ticket;
+        leaf_last, logits, vhid, pol_feat, T_table, log_table, sqrt_table, noise_off, cnt, next_game, active;
     // per-episode buffers
     DevBuf dbg;
     DevBuf noise, u, rec_planes, rec_last, rec_action, rec_mover, rec_pi, rec_visits, g_nply, g_result, src_index;
-    int episode_games = 0, episode_capacity = 0;
+    int episode_games = 0;
     int64_t tape_len = 0;          // doubles per game in the noise tape
     bool have_episode = false;
     std::vector<int> h_nply, h_result;
@@ -391,7 +390,7 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
     ALLOC(leaf_kind, B * 4); ALLOC(leaf, B * 8 * sizeof(u64)); ALLOC(leaf_last, B * 4);
     ALLOC(logits, B * (size_t)e->RW * 4); ALLOC(vhid, B * 64 * 4);
     ALLOC(pol_feat, B * (size_t)((((cfg->model == AZ_MODEL_RESNET ? 3 : 6) * e->nn + 3) / 4) * 4) * 4);   // feature rows [B][FROW], zero tail stays zero
-    ALLOC(cnt, B * 4 * sizeof(unsigned long long)); ALLOC(next_game, 16); ALLOC(active, 16); ALLOC(ticket, 16);
+    ALLOC(cnt, B * 4 * sizeof(unsigned long long)); ALLOC(next_game, 16); ALLOC(active, 16);
     ALLOC(T_table, (size_t)(e->nn + 4) * sizeof(double));
 #ifdef AZ_STAMPS
     ALLOC(dbg, (B * 16 + 4096 * 32) * sizeof(unsigned long long));
@@ -439,8 +438,8 @@ extern "C" void az_destroy(az_engine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     DevBuf *all[] = {&e->board, &e->s_game, &e->s_ply, &e->s_player, &e->s_last, &e->s_status, &e->s_net, &e->edges,
                      &e->rows_used, &e->path, &e->depth, &e->leaf_kind, &e->leaf, &e->leaf_last, &e->logits, &e->vhid,
-                     &e->pol_feat, &e->val_feat, &e->T_table, &e->log_table, &e->sqrt_table, &e->noise_off, &e->cnt,
-                     &e->next_game, &e->active, &e->ticket, &e->noise, &e->u, &e->rec_planes, &e->rec_last, &e->rec_action,
+                     &e->pol_feat, &e->T_table, &e->log_table, &e->sqrt_table, &e->noise_off, &e->cnt,
+                     &e->next_game, &e->active, &e->noise, &e->u, &e->rec_planes, &e->rec_last, &e->rec_action,
                      &e->rec_mover, &e->rec_pi, &e->rec_visits, &e->g_nply, &e->g_result, &e->src_index};
     for (DevBuf *b : all) dev_free(*b);
     for (int s = 0; s < 2; s++) {

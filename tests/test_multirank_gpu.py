@@ -1,0 +1,52 @@
+"""world_size-2 run of the real engine on ONE GPU (ranks share the device, gloo collectives): game sharding, per-game
+seeding and the episode-end record exchange give every rank the same examples as a single process."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests.util import ROOT
+
+WORKER = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as td
+world = int(os.environ.get("WORLD_SIZE", "1"))
+if world > 1:
+    td.init_process_group("gloo")
+from alphazero_piskvorky_amd import net
+from alphazero_piskvorky_amd.controller import NeuralNetworkController
+from alphazero_piskvorky_amd.self_play import SelfPlayManager
+from alphazero_piskvorky_amd.weights import synthetic_state_dict
+m = net.GomokuNet(board_size=5)
+m.load_state_dict({k: torch.tensor(v) for k, v in synthetic_state_dict(5).items()})
+ctrl = NeuralNetworkController(m, device="cuda:0")
+data = SelfPlayManager(ctrl, "cuda:0", mcts_params={"num_simulations": 24}, concurrent_games=8, seed=2024).generate_self_play(13)
+rank = td.get_rank() if world > 1 else 0
+np.savez(sys.argv[2] + f".{rank}.npz", s=np.stack([d[0].numpy() for d in data]), p=np.stack([d[1] for d in data]),
+         z=np.array([d[2] for d in data]))
+if world > 1:
+    td.barrier(); td.destroy_process_group()
+'''
+
+
+def test_selfplay_manager_two_ranks_equals_single_process(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    single = str(tmp_path / "single")
+    subprocess.run([sys.executable, str(script), ROOT, single], check=True, env=env, timeout=300, stdout=subprocess.DEVNULL)
+    multi = str(tmp_path / "multi")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                    "--master-addr", "127.0.0.1", "--master-port", "29733", str(script), ROOT, multi],
+                   check=True, env=env, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    ref = np.load(single + ".0.npz")
+    for rank in (0, 1):
+        got = np.load(multi + f".{rank}.npz")
+        assert got["z"].shape == ref["z"].shape and len(ref["z"]) > 0
+        for key in ("s", "p", "z"):
+            assert np.array_equal(got[key], ref[key]), f"rank {rank}: {key} differs from the single-process episode"
