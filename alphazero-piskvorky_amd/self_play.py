@@ -51,6 +51,21 @@ class SelfPlayManager:
     def generate_self_play(self, num_games: int, num_workers: int = None, flatten=False) -> list:
         """Returns list[(state f32 (4,n,n) CPU tensor, pi f32 (n,n) ndarray, z int)] in (game, ply, k) order
         (self_play.py:110-159; num_workers / flatten are accepted and unused like the reference's `flatten`)."""
+        packed, total, eng, dev, n = self.generate_packed(num_games)
+        aug = self.augmentation
+        states = torch.empty((total * aug, 4, n, n), dtype=torch.float32, device=dev)
+        pis = torch.empty((total * aug, n, n), dtype=torch.float32, device=dev)
+        zs = torch.empty(total * aug, dtype=torch.float32, device=dev)
+        if total:
+            eng.examples_from_packed(packed.data_ptr(), total, aug, states.data_ptr(), pis.data_ptr(), zs.data_ptr())
+        states, pis, zs = states.cpu(), pis.cpu().numpy(), zs.cpu().numpy().astype(np.int64)
+        print(f"[SelfPlayManager] Collected {len(zs)} examples from {num_games} games.")
+        return [(states[i], pis[i], int(zs[i])) for i in range(len(zs))]
+
+    def generate_packed(self, num_games: int):
+        """The same episode, but the result stays on the device as packed records (one per position, all ranks'
+        records after the exchange): (uint8 tensor, record count, engine, device, n).  Feed it to
+        device_replay.DeviceReplayBuffer.extend_packed to train without materialising Python tuples."""
         import torch.distributed as td
         n = self.controller.net.board_size
         k = min(_c.WIN_LENGTH, n)
@@ -72,13 +87,4 @@ class SelfPlayManager:
         else:
             eng.last_records = 0
         packed, counts = parallel.gather_packed_records(eng, dev)
-        total = int(sum(counts))
-        aug = self.augmentation
-        states = torch.empty((total * aug, 4, n, n), dtype=torch.float32, device=dev)
-        pis = torch.empty((total * aug, n, n), dtype=torch.float32, device=dev)
-        zs = torch.empty(total * aug, dtype=torch.float32, device=dev)
-        if total:
-            eng.examples_from_packed(packed.data_ptr(), total, aug, states.data_ptr(), pis.data_ptr(), zs.data_ptr())
-        states, pis, zs = states.cpu(), pis.cpu().numpy(), zs.cpu().numpy().astype(np.int64)
-        print(f"[SelfPlayManager] Collected {len(zs)} examples from {num_games} games.")
-        return [(states[i], pis[i], int(zs[i])) for i in range(len(zs))]
+        return packed, int(sum(counts)), eng, dev, n

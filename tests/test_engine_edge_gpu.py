@@ -159,3 +159,37 @@ def test_full_size_15x15_first_plies_invariants():
         assert np.array_equal(rec["actions"][sl], r["actions"]) and np.array_equal(rec["visits"][sl], r["visits"])
         assert np.array_equal(rec["pis"][sl], r["pis"]) and np.array_equal(rec["boards"][sl], r["boards"])
     eng.close()
+
+
+def test_full_size_15x15_400sims_episode_with_refill():
+    """The BASELINE headline shape end to end: 15x15/5, 400 sims, 1024 slots (4 engines), 1100 games so that slots are
+    refilled; every game is replayed with the oracle's rules and every record is checked."""
+    n, k, S, G = 15, 5, 400, 1100
+    eng = az.MultiEngine(n, k, S, 1024, engines=4, log_table=orc.numpy_log_table(S))
+    eng.load_weights(weights_from_fixture(n, "seeded"), 0)
+    c = eng.selfplay(G, seed0=2718)
+    rec = eng.records(); nply, res = eng.games()
+    assert c["games"] == G and c["plies"] == int(nply.sum()) and (nply >= 9).all()      # a win needs at least 9 plies
+    assert c["simulations"] == S * c["plies"] and c["expansions"] + c["terminal_hits"] == c["simulations"]
+    _check_episode_invariants(n, k, S, rec, nply, res, G)
+    eng.close()
+
+
+def test_generate_packed_feeds_the_device_replay_ring():
+    import torch
+    from alphazero_piskvorky_amd import net
+    from alphazero_piskvorky_amd.controller import NeuralNetworkController
+    from alphazero_piskvorky_amd.device_replay import DeviceReplayBuffer
+    from alphazero_piskvorky_amd.self_play import SelfPlayManager
+    m = net.GomokuNet(board_size=5)
+    m.load_state_dict({kk: torch.tensor(v) for kk, v in weights_from_fixture(5, "ckpt_saved").items()})
+    ctrl = NeuralNetworkController(m, device="cuda:0")
+    mgr = SelfPlayManager(ctrl, "cuda:0", mcts_params={"num_simulations": 30}, concurrent_games=16, seed=5)
+    packed, total, eng, dev, n = mgr.generate_packed(20)
+    assert total == mgr.last_counters["records"] and packed.numel() >= total * eng.record_bytes
+    buf = DeviceReplayBuffer(eng, capacity=10_000, device="cuda:0", seed=0)
+    buf.extend_packed(packed, total)
+    s, p, z = buf.sample_batch(128)
+    assert s.shape == (128, 4, 5, 5) and p.shape == (128, 5, 5) and z.shape == (128,)
+    assert torch.allclose(p.sum(dim=(1, 2)), torch.ones(128, device=p.device), atol=1e-5)
+    assert np.isfinite(ctrl.train_step(s, p, z)["loss"])
