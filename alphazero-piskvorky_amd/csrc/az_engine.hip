@@ -13,8 +13,9 @@
 #include <thread>
 #include <vector>
 
+#define AZ_ENGINE_TU 1
 #include "../../include/az_engine.h"
-#include "az_net.h"
+#include "az_launch.h"
 
 namespace azrng {
 void selfplay_tapes_parallel(uint64_t seed0, int g0, int count, int nn, double alpha, int max_plies, double *noise,
@@ -42,6 +43,7 @@ struct az_engine {
     int n = 0, nn = 0, RW = 0, R = 0, PATH = 0, num_cus = 256;
     std::string err;
     hipStream_t stream = nullptr;
+    const SizeOps *ops = nullptr;
     DevState d{};
     // per-engine buffers
     DevBuf board, s_game, s_ply, s_player, s_last, s_status, s_net, edges, rows_used, path, depth, leaf_kind, leaf,
@@ -67,6 +69,19 @@ struct az_engine {
     std::vector<hipEvent_t> ev;
     bool profile = true;
 };
+
+static LaunchCtx ctx_of_impl(const az_engine *e)
+{
+    LaunchCtx c{};
+    c.stream = e->stream;
+    c.d = e->d;
+    for (int i = 0; i < 2; i++) { c.w[i] = e->net[i].w; c.rw[i] = e->net[i].rw; }
+    c.model = e->cfg.model;
+    c.synthetic = e->cfg.eval_kind == AZ_EVAL_SYNTHETIC;
+    c.feat = (float *)e->pol_feat.p;
+    c.dbg = (unsigned long long *)e->dbg.p;
+    return c;
+}
 
 // ------------------------------------------------------------------------------------------------
 static int fail(az_engine *e, int code, const char *fmt, ...)
@@ -163,70 +178,20 @@ static std::vector<float> pack_fc(const float *w, int nout, int kin)
 }
 
 // ------------------------------------------------------------------------------------------------
-// kernel dispatch by board size
+// kernel dispatch by board size: one translation unit per size (az_kernels.hip), selected once at az_create
 // ------------------------------------------------------------------------------------------------
-template <int N>
-static void launch_trunk_only(az_engine *e, int net_id)
+const SizeOps *az_size_ops(int n)
 {
-    if (e->cfg.model == AZ_MODEL_RESNET) {
-        typedef ResGeo<N> G;
-        dim3 gt((e->d.B + G::G - 1) / G::G), bt(G::NW * 64);
-        hipLaunchKernelGGL(k_trunk_res<N>, gt, bt, 0, e->stream, e->d, e->net[net_id].rw, net_id, (float *)e->pol_feat.p);
-    } else {
-        typedef NetGeo<N> G;
-        dim3 gt((e->d.B + G::G - 1) / G::G), bt(G::NW * 64);
-        hipLaunchKernelGGL(k_trunk<N>, gt, bt, 0, e->stream, e->d, e->net[net_id].w, net_id, (float *)e->pol_feat.p, (unsigned long long *)e->dbg.p);
+    switch (n) {
+    case 3: return az_size_ops_3();   case 4: return az_size_ops_4();   case 5: return az_size_ops_5();
+    case 6: return az_size_ops_6();   case 7: return az_size_ops_7();   case 8: return az_size_ops_8();
+    case 9: return az_size_ops_9();   case 10: return az_size_ops_10(); case 11: return az_size_ops_11();
+    case 12: return az_size_ops_12(); case 13: return az_size_ops_13(); case 14: return az_size_ops_14();
+    case 15: return az_size_ops_15();
+    default: return nullptr;
     }
-}
-template <int N>
-static void launch_fc_only(az_engine *e, int net_id)
-{
-    unsigned long long *dbgfc = e->dbg.p ? (unsigned long long *)e->dbg.p + (size_t)e->d.B * 16 : nullptr;
-    if (e->cfg.model == AZ_MODEL_RESNET) {
-        typedef ResGeo<N> G;
-        dim3 gf((e->d.B + 15) / 16, G::NSPLIT), bf(G::FCW * 64);
-        hipLaunchKernelGGL(k_fc<G>, gf, bf, 0, e->stream, e->d, e->net[net_id].w, net_id, (const float *)e->pol_feat.p, dbgfc);
-    } else {
-        typedef NetGeo<N> G;
-        dim3 gf((e->d.B + 15) / 16, G::NSPLIT), bf(G::FCW * 64);
-        hipLaunchKernelGGL(k_fc<G>, gf, bf, 0, e->stream, e->d, e->net[net_id].w, net_id, (const float *)e->pol_feat.p, dbgfc);
-    }
-}
-template <int N>
-static void launch_net(az_engine *e, int net_id)
-{
-    launch_trunk_only<N>(e, net_id);
-    launch_fc_only<N>(e, net_id);
-}
-template <int N>
-static void launch_step(az_engine *e, int rootN, int do_select)
-{
-    dim3 g((e->d.B + 3) / 4), b(256);
-    const size_t lds = (size_t)(e->d.S + 2) * sizeof(double);   // sqrt table
-    if (e->cfg.eval_kind == AZ_EVAL_SYNTHETIC)
-        hipLaunchKernelGGL((k_step<N, true>), g, b, lds, e->stream, e->d, rootN, do_select);
-    else
-        hipLaunchKernelGGL((k_step<N, false>), g, b, lds, e->stream, e->d, rootN, do_select);
-}
-template <int N>
-static void launch_move(az_engine *e)
-{
-    dim3 g((e->d.B + 3) / 4), b(256);
-    hipLaunchKernelGGL(k_move<N>, g, b, 0, e->stream, e->d);
-}
-template <int N>
-static void launch_eval_tail(az_engine *e, int count, float *pol, float *val)
-{
-    dim3 g((count + 3) / 4), b(256);
-    hipLaunchKernelGGL(k_eval_tail<N>, g, b, 0, e->stream, e->d, count, pol, val);
 }
 
-#define DISPATCH_N(e, fn, ...)                                   \
-    do {                                                         \
-        if ((e)->n == 5) fn<5>(__VA_ARGS__);                     \
-        else if ((e)->n == 9) fn<9>(__VA_ARGS__);                \
-        else fn<15>(__VA_ARGS__);                                \
-    } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // packed records + examples (self_play.py:94-108 augmentation fused into the encode)
@@ -354,8 +319,8 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
 {
     if (!cfg || !out) return fail(nullptr, AZ_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (cfg->board_size != 5 && cfg->board_size != 9 && cfg->board_size != 15)
-        return fail(nullptr, AZ_ERR_INVALID, "board_size must be 5, 9 or 15 (got %d)", cfg->board_size);
+    if (cfg->board_size < 3 || cfg->board_size > 15)
+        return fail(nullptr, AZ_ERR_INVALID, "board_size must be 3..15 (got %d)", cfg->board_size);
     if (cfg->win_length < 2 || cfg->win_length > cfg->board_size) return fail(nullptr, AZ_ERR_INVALID, "bad win_length");
     if (cfg->num_simulations < 1 || cfg->num_simulations > 1024) return fail(nullptr, AZ_ERR_INVALID, "num_simulations must be 1..1024");
     if (cfg->slots < 1 || cfg->slots > 65536) return fail(nullptr, AZ_ERR_INVALID, "slots must be 1..65536");
@@ -371,6 +336,7 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
     e->RW = (e->nn + 63) / 64 * 64;
     e->R = cfg->num_simulations + 1;
     e->PATH = e->nn + 1;
+    e->ops = az_size_ops(e->n);
     hipError_t hr = hipSetDevice(cfg->device);
     if (hr == hipSuccess) hr = hipStreamCreate(&e->stream);
     if (hr != hipSuccess) {
@@ -601,6 +567,7 @@ static int episode_plies(az_engine *e, int max_steps)
         e->ev.push_back(ev);
     }
     const int nnets = r.arena ? 2 : 1;
+    const LaunchCtx lc = ctx_of_impl(e);
     auto t0 = std::chrono::steady_clock::now();
     for (int step = 0; step < max_steps && r.active > 0; step++) {
         hipLaunchKernelGGL(k_begin, dim3((d.B + 255) / 256), dim3(256), 0, e->stream, d);
@@ -608,17 +575,17 @@ static int episode_plies(az_engine *e, int max_steps)
             if (net) {
                 const int ei = 3 * (t + 1);
                 if (prof) HIPCHECK(e, hipEventRecord(e->ev[ei], e->stream));
-                for (int id = 0; id < nnets; id++) DISPATCH_N(e, launch_trunk_only, e, id);
+                for (int id = 0; id < nnets; id++) e->ops->trunk(lc, id);
                 if (prof) HIPCHECK(e, hipEventRecord(e->ev[ei + 1], e->stream));
-                for (int id = 0; id < nnets; id++) DISPATCH_N(e, launch_fc_only, e, id);
+                for (int id = 0; id < nnets; id++) e->ops->fc(lc, id);
                 if (prof) HIPCHECK(e, hipEventRecord(e->ev[ei + 2], e->stream));
                 r.c.trunk_launches += nnets;
             }
             // t = -1 consumes the root evaluation (root N = 0 for the first selection); t >= 0 consumes simulation t
-            DISPATCH_N(e, launch_step, e, t + 1, (t + 1 < S) ? 1 : 0);
+            e->ops->step(lc, t + 1, (t + 1 < S) ? 1 : 0);
             r.c.steps++;
         }
-        DISPATCH_N(e, launch_move, e);
+        e->ops->move(lc);
         r.c.plies += r.active;
         if (r.preset) {
             r.active = 0;
@@ -904,8 +871,12 @@ extern "C" int az_net_eval(az_engine *e, int slot, int count, const uint8_t *boa
         if (hr == hipSuccess) hr = hipMemcpy(e->s_net.p, nets.data(), (size_t)B * 4, hipMemcpyHostToDevice);
         if (hr == hipSuccess) hr = hipMemcpy(e->leaf_last.p, ll.data(), (size_t)B * 4, hipMemcpyHostToDevice);
         if (hr != hipSuccess) { rc = fail(e, AZ_ERR_HIP, "az_net_eval upload: %s", hipGetErrorString(hr)); break; }
-        DISPATCH_N(e, launch_net, e, slot);
-        DISPATCH_N(e, launch_eval_tail, e, cnt, (float *)dpol.p, (float *)dval.p);
+        {
+            const LaunchCtx lc = ctx_of_impl(e);
+            e->ops->trunk(lc, slot);
+            e->ops->fc(lc, slot);
+            e->ops->eval_tail(lc, cnt, (float *)dpol.p, (float *)dval.p);
+        }
         hr = hipStreamSynchronize(e->stream);
         if (hr == hipSuccess) hr = hipGetLastError();
         if (hr == hipSuccess && logits)

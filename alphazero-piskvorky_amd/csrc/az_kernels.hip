@@ -1,0 +1,68 @@
+// az_kernels.hip -- the size-templated kernels instantiated for ONE board size (compile with -DAZ_N=n).
+#include <hip/hip_runtime.h>
+#include "az_launch.h"
+
+#ifndef AZ_N
+#error "compile with -DAZ_N=<board size>"
+#endif
+#define AZ_CAT2(a, b) a##b
+#define AZ_CAT(a, b) AZ_CAT2(a, b)
+
+namespace {
+constexpr int N = AZ_N;
+
+void trunk(const LaunchCtx &c, int net_id)
+{
+    if (c.model == 1) {
+        typedef ResGeo<N> G;
+        dim3 gt((c.d.B + G::G - 1) / G::G), bt(G::NW * 64);
+        hipLaunchKernelGGL(k_trunk_res<N>, gt, bt, 0, c.stream, c.d, c.rw[net_id], net_id, c.feat);
+    } else {
+        typedef NetGeo<N> G;
+        dim3 gt((c.d.B + G::G - 1) / G::G), bt(G::NW * 64);
+        hipLaunchKernelGGL(k_trunk<N>, gt, bt, 0, c.stream, c.d, c.w[net_id], net_id, c.feat, c.dbg);
+    }
+}
+
+void fc(const LaunchCtx &c, int net_id)
+{
+    unsigned long long *dbgfc = c.dbg ? c.dbg + (size_t)c.d.B * 16 : nullptr;
+    if (c.model == 1) {
+        typedef ResGeo<N> G;
+        dim3 gf((c.d.B + 15) / 16, G::NSPLIT), bf(G::FCW * 64);
+        hipLaunchKernelGGL(k_fc<G>, gf, bf, 0, c.stream, c.d, c.w[net_id], net_id, (const float *)c.feat, dbgfc);
+    } else {
+        typedef NetGeo<N> G;
+        dim3 gf((c.d.B + 15) / 16, G::NSPLIT), bf(G::FCW * 64);
+        hipLaunchKernelGGL(k_fc<G>, gf, bf, 0, c.stream, c.d, c.w[net_id], net_id, (const float *)c.feat, dbgfc);
+    }
+}
+
+void step(const LaunchCtx &c, int rootN, int do_select)
+{
+    dim3 g((c.d.B + 3) / 4), b(256);
+    const size_t lds = (size_t)(c.d.S + 2) * sizeof(double);   // sqrt table
+    if (c.synthetic)
+        hipLaunchKernelGGL((k_step<N, true>), g, b, lds, c.stream, c.d, rootN, do_select);
+    else
+        hipLaunchKernelGGL((k_step<N, false>), g, b, lds, c.stream, c.d, rootN, do_select);
+}
+
+void move(const LaunchCtx &c)
+{
+    dim3 g((c.d.B + 3) / 4), b(256);
+    hipLaunchKernelGGL(k_move<N>, g, b, 0, c.stream, c.d);
+}
+
+void eval_tail_l(const LaunchCtx &c, int count, float *pol, float *val)
+{
+    dim3 g((count + 3) / 4), b(256);
+    hipLaunchKernelGGL(k_eval_tail<N>, g, b, 0, c.stream, c.d, count, pol, val);
+}
+}   // namespace
+
+const SizeOps *AZ_CAT(az_size_ops_, AZ_N)()
+{
+    static const SizeOps ops = {trunk, fc, step, move, eval_tail_l};
+    return &ops;
+}

@@ -1,0 +1,28 @@
+// az_launch.h -- per-board-size kernel launchers.  Every board size n = 3..15 is its own translation unit
+// (az_kernels.hip compiled with -DAZ_N=n, in parallel); the engine dispatches through this table.
+#pragma once
+#include "az_net.h"
+
+struct LaunchCtx {
+    hipStream_t stream;
+    DevState d;
+    NetWeights w[2];
+    ResWeights rw[2];
+    int model;          // AZ_MODEL_PLAIN | AZ_MODEL_RESNET
+    int synthetic;      // AZ_EVAL_SYNTHETIC
+    float *feat;
+    unsigned long long *dbg;
+};
+
+struct SizeOps {
+    void (*trunk)(const LaunchCtx &, int net_id);
+    void (*fc)(const LaunchCtx &, int net_id);
+    void (*step)(const LaunchCtx &, int rootN, int do_select);
+    void (*move)(const LaunchCtx &);
+    void (*eval_tail)(const LaunchCtx &, int count, float *policy, float *value);
+};
+
+const SizeOps *az_size_ops(int n);     // nullptr for unsupported sizes
+#define AZ_DECL_OPS(n) const SizeOps *az_size_ops_##n();
+AZ_DECL_OPS(3) AZ_DECL_OPS(4) AZ_DECL_OPS(5) AZ_DECL_OPS(6) AZ_DECL_OPS(7) AZ_DECL_OPS(8) AZ_DECL_OPS(9)
+AZ_DECL_OPS(10) AZ_DECL_OPS(11) AZ_DECL_OPS(12) AZ_DECL_OPS(13) AZ_DECL_OPS(14) AZ_DECL_OPS(15)

@@ -36,10 +36,27 @@ struct NetWeights {
 
 __host__ __device__ constexpr int up16(int x) { return x + ((16 - (x % 32) + 32) % 32); }   // smallest y >= x, y == 16 (mod 32)
 
+// Boards per trunk workgroup for an n x n board: as many as fit the LDS budget, at most 4 (so that 1024 games still
+// give >= 256 workgroups).  chan = LDS floats per padded cell (96 plain net: 32+64 channels; 128 ResidualBlock net).
+__host__ __device__ constexpr int trunk_lds_floats(int n, int g, int chan)
+{
+    const int cs = up16(g * (n + 2) * (n + 2));
+    const int mr = ((g * n * n + 15) / 16) * 16;
+    const int a = chan * cs, b = chan == 96 ? 128 * up16(mr) : 0;     // plain net: the conv3 image overlays the inputs
+    return a > b ? a : b;
+}
+__host__ __device__ constexpr int pick_boards(int n, int chan, int budget)
+{
+    int g = 1;
+    for (int t = 2; t <= 4; t++)
+        if (trunk_lds_floats(n, t, chan) <= budget) g = t;
+    return g;
+}
+
 template <int N>
 struct NetGeo {
     static constexpr int n = N, nn = N * N, PW = N + 2, PP = PW * PW;
-    static constexpr int G = N == 15 ? 1 : (N == 9 ? 3 : 4);     // boards per workgroup (5x5: 4 -> 256 workgroups at 1024 games, 2 per CU)
+    static constexpr int G = pick_boards(N, 96, 36500);            // boards per workgroup: 1 at n >= 12, 2 at 10-11, 3 at 8-9, 4 below
     static constexpr int M = G * nn;                               // real GEMM columns (board cells)
     // 16-cell MFMA tiles.  n = 15: one tile = one board row + its right padding cell (contiguous in the padded
     // image, so the 16 lanes of a fragment hit 16 consecutive LDS banks); other sizes: 16 consecutive cells.
@@ -71,7 +88,7 @@ struct NetGeo {
 template <int N>
 struct ResGeo {
     static constexpr int n = N, nn = N * N, PW = N + 2, PP = PW * PW;
-    static constexpr int G = N == 15 ? 1 : (N == 9 ? 2 : 4);     // boards per workgroup (LDS: 2 x 64 channels)
+    static constexpr int G = pick_boards(N, 128, 39500);           // boards per workgroup (LDS: 2 x 64 channels)
     static constexpr int M = G * nn;
     static constexpr bool ROWT = (N == 15);
     static constexpr int MT = ROWT ? G * N : (M + 15) / 16, MR = MT * 16;
@@ -149,7 +166,7 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
 #pragma unroll
         for (int i = 0; i < MTW; i++) {
             int mt = mg + i * MG;
-            int m = (mt < G::MT ? mt : mg) * 16 + r16;      // a surplus tile aliases the first one (never written back)
+            int m = (mt < G::MT ? mt : 0) * 16 + r16;       // a surplus tile aliases tile 0 (computed, never written back)
             rb[i] = (int)wpos[m] - (G::PW + 1) + q * G::CS;
         }
         float bk[NTW][12];
@@ -180,7 +197,7 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
 #pragma unroll
         for (int i = 0; i < MTW; i++) {
             int mt = mg + i * MG;
-            int m = (mt < G::MT ? mt : mg) * 16 + r16;
+            int m = (mt < G::MT ? mt : 0) * 16 + r16;
             ra[i] = (int)wpos[m] - (G::PW + 1) + q * G::CS;
         }
         float4 a0[MTW], a1[MTW];
@@ -359,7 +376,7 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk(DevState d, NetWeights w, 
         for (int i = 0; i < HT; i++) {
             const int mt = wave + AZ_NW * i;
             acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            ip[i] = lds + q * G::CS3 + (mt < G::MT ? mt : wave) * 16 + r16;
+            ip[i] = lds + q * G::CS3 + (mt < G::MT ? mt : 0) * 16 + r16;
         }
 #pragma unroll
         for (int s4 = 0; s4 < 8; s4++) {
@@ -470,6 +487,7 @@ __global__ __launch_bounds__(ResGeo<N>::NW * 64) void k_trunk_res(DevState d, Re
     __syncthreads();
     for (int i = tid; i < 3 * G::CS; i += NTH) B[i] = 0.0f;     // the planes would alias padding cells of the packed image
     __syncthreads();
+#pragma unroll 1
     for (int blk = 0; blk < 3; blk++) {
         conv_layer<G, 64, 64, CONV_OUT_PACKED>(A, B, w.blk[2 * blk], w.blkb[2 * blk], wpos, cellof, wave, lane);
         __syncthreads();
@@ -550,6 +568,7 @@ __global__ __launch_bounds__(G::FCW * 64) void k_fc(DevState d, NetWeights w, in
     // the LDS tail [FROW, FSTR) is zeroed: the padded k-steps of the last weight group read it (times zero weights)
     constexpr int V = G::FROW / 4, VS = G::FSTR / 4;
     static_assert(G::FNEED <= G::FSTR, "feature tile too narrow");
+    static_assert(16 * G::FSTR * 4 <= 150 * 1024, "k_fc feature tile exceeds LDS");
     constexpr int NTH = G::FCW * 64;
     constexpr int U = (16 * VS + NTH - 1) / NTH;
     float4 tmp[U];

@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256) void k_eval_tail(DevState d, int count, float 
     if (lane == 0) value[b] = v;
 }
 
+#ifdef AZ_ENGINE_TU   // size-independent kernels live in the engine translation unit only
 // ------------------------------------------------------------------------------------------------
 // k_begin: the root of every active slot becomes the pending evaluation (mcts.py:106-109)
 // ------------------------------------------------------------------------------------------------
@@ -148,6 +149,8 @@ __global__ void k_begin(DevState d)
     d.depth[b] = 0;
     d.s_net[b] = d.arena ? (pl == 1 ? 0 : 1) : 0;   // evaluator.py:73-79: each side searches with its own net
 }
+
+#endif  // AZ_ENGINE_TU
 
 // ------------------------------------------------------------------------------------------------
 // k_step: consume the evaluation of the pending leaf (expand + backup), then select the next leaf.
@@ -518,6 +521,7 @@ __global__ __launch_bounds__(256) void k_move(DevState d)
     }
 }
 
+#ifdef AZ_ENGINE_TU
 // ------------------------------------------------------------------------------------------------
 // k_refill: finished/idle slots receive the next game ids in slot order (ballot + prefix sum),
 //           replacing the task queue of self_play.py:114-118,41-45.  One block of 1024 threads.
@@ -579,3 +583,4 @@ __global__ void k_set_position(DevState d, int slot, int game, int player, int l
     d.s_status[slot] = SLOT_ACTIVE;
     d.leaf_kind[slot] = LEAF_NONE;
 }
+#endif  // AZ_ENGINE_TU

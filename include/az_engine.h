@@ -46,7 +46,7 @@ enum { AZ_MODEL_PLAIN = 0, AZ_MODEL_RESNET = 1 };  /* net.py GomokuNet | Residua
 
 /* Hyper-parameters the reference keeps in constants.py / MCTS.__init__ (mcts.py:87-97). */
 typedef struct {
-    int32_t board_size;        /* constants.py:2  BOARD_SIZE   (5, 9 or 15)                      */
+    int32_t board_size;        /* constants.py:2  BOARD_SIZE   (3 .. 15)                         */
     int32_t win_length;        /* constants.py:3  WIN_LENGTH                                     */
     int32_t num_simulations;   /* mcts.py:89      num_simulations (<= 1024)                      */
     int32_t slots;             /* concurrent games resident on this GPU                          */

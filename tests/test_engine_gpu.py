@@ -273,7 +273,7 @@ def test_examples_pack_and_augmentation():
 
 def test_error_paths():
     with pytest.raises(az.AzError):
-        az.Engine(7, 4, 10, 4)                      # unsupported board size
+        az.Engine(16, 5, 10, 4)                     # unsupported board size (3..15)
     e = _engine(5, 4, 10, slots=2)
     with pytest.raises(az.AzError):
         e.selfplay(1)                               # net evaluator without weights
