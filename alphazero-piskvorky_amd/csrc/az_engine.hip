@@ -182,6 +182,11 @@ static std::vector<float> pack_fc(const float *w, int nout, int kin)
 // ------------------------------------------------------------------------------------------------
 const SizeOps *az_size_ops(int n)
 {
+#ifdef AZ_ONLY_N          // experiment builds with a single board size
+#define AZ_OPS_CAT2(a, b) a##b
+#define AZ_OPS_CAT(a, b) AZ_OPS_CAT2(a, b)
+    return n == AZ_ONLY_N ? AZ_OPS_CAT(az_size_ops_, AZ_ONLY_N)() : nullptr;
+#endif
     switch (n) {
     case 3: return az_size_ops_3();   case 4: return az_size_ops_4();   case 5: return az_size_ops_5();
     case 6: return az_size_ops_6();   case 7: return az_size_ops_7();   case 8: return az_size_ops_8();
@@ -337,6 +342,10 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
     e->R = cfg->num_simulations + 1;
     e->PATH = e->nn + 1;
     e->ops = az_size_ops(e->n);
+    if (!e->ops) {
+        delete e;
+        return fail(nullptr, AZ_ERR_INVALID, "board size %d is not built into this library", cfg->board_size);
+    }
     hipError_t hr = hipSetDevice(cfg->device);
     if (hr == hipSuccess) hr = hipStreamCreate(&e->stream);
     if (hr != hipSuccess) {

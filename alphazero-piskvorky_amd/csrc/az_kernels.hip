@@ -19,7 +19,8 @@ void trunk(const LaunchCtx &c, int net_id)
         hipLaunchKernelGGL(k_trunk_res<N>, gt, bt, 0, c.stream, c.d, c.rw[net_id], net_id, c.feat);
     } else {
         typedef NetGeo<N> G;
-        dim3 gt((c.d.B + G::G - 1) / G::G), bt(G::NW * 64);
+        const int ngroups = (c.d.B + G::G - 1) / G::G;
+        dim3 gt(AZ_SEQ == 0 ? (ngroups < 256 ? ngroups : 256) : (ngroups + AZ_SEQ - 1) / AZ_SEQ), bt(G::NW * 64);
         hipLaunchKernelGGL(k_trunk<N>, gt, bt, 0, c.stream, c.d, c.w[net_id], net_id, c.feat, c.dbg);
     }
 }

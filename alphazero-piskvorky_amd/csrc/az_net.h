@@ -1,9 +1,11 @@
-// az_net.h -- GomokuNet forward (net.py:55-72) as two HIP kernels for gfx950.
+// az_net.h -- the policy/value net forward as HIP kernels for gfx950.
 //
-//  k_trunk : leaf encode (games.py:86-129) -> conv1 -> conv2 -> conv3 -> policy/value 1x1 convs, one
-//            workgroup per group of G boards, every activation resident in LDS (zero-padded planes, so
-//            the 3x3 im2col is "base + constant offset"), contraction on v_mfma_f32_16x16x4_f32.
-//  k_fc    : policy_fc and value_fc1 as a batched GEMM over boards, same MFMA.
+//  k_trunk     : GomokuNet (net.py:55-72): leaf encode (games.py:86-129) -> conv1 -> conv2 -> conv3 -> policy/value
+//                1x1 convs.  One workgroup per group of G boards, every activation resident in LDS: zero-padded
+//                images, so the 3x3 im2col is "base + constant offset"; conv2/conv3 inputs in a packed layout read
+//                with ds_read_b128; contraction on v_mfma_f32_16x16x4_f32 with the weights as the A operand.
+//  k_trunk_res : the ResidualBlock variant (BASELINE config 5): stem + 3 residual blocks + 1x1 heads, same machinery.
+//  k_fc        : policy_fc and value_fc1 as a batched GEMM over boards, same MFMA, one k-ordered chain per output.
 // softmax / value_fc2 / tanh are fused into the tree kernel that consumes them (az_tree.h).
 //
 // Numerics: every output element is ONE k-ordered fp32 fma chain from +0 (what the f32 MFMA computes,
@@ -21,11 +23,11 @@
 #ifndef AZ_NW
 #define AZ_NW 8          // waves per trunk workgroup
 #endif
+#ifndef AZ_SEQ
+#define AZ_SEQ 1         // board groups per trunk workgroup (0 = persistent grid stride); all variants measure the same
+#endif
 #ifndef AZ_NTW
 #define AZ_NTW 1         // channel tiles per wave in the conv layers (1: 15 cell tiles per wave, no surplus tile)
-#endif
-#ifndef AZ_SCHED
-#define AZ_SCHED 0       // 0: 1 MFMA : 1 LDS read interleave, 1: read burst then MFMA burst
 #endif
 
 struct NetWeights {
@@ -279,20 +281,19 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
     }
 }
 
+// The work of one board group.  When this is inlined into a loop over groups the compiler hoists the layers'
+// loop-invariant address arithmetic across iterations, runs out of VGPRs (256 + scratch) and the kernel slows down by
+// 20 %; callers in a loop therefore pass a thread id made opaque per iteration (asm volatile), which pins that
+// arithmetic inside the iteration.  (Out-of-line calls are worse: the call ABI forces spills.)
 template <int N>
-__global__ __launch_bounds__(AZ_NW * 64) void k_trunk(DevState d, NetWeights w, int net_id, float *__restrict__ feat,
-                                               unsigned long long *dbg)
+__device__ __forceinline__ void trunk_group(const DevState &d, const NetWeights &w, int net_id, float *__restrict__ feat,
+                                                      unsigned long long *dbg, int grp, float *lds, unsigned short *wpos,
+                                                      unsigned short *cellof, int *any_active_p, int tid)
 {
     typedef NetGeo<N> G;
-    __shared__ __attribute__((aligned(16))) float lds[G::LDSF];
-    __shared__ unsigned short wpos[G::MR];     // centre position of tile cell m in the padded image
-    __shared__ unsigned short cellof[G::MR];   // g*nn + cell index, 0xFFFF for a junk lane
-    __shared__ int any_active;
-    const int tid = threadIdx.x, lane = tid & 63;
+    int &any_active = *any_active_p;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // One workgroup per board group.  (A persistent grid-stride / ticket variant measured 6 % slower: 256 CUs marching
-    // through identical phases in lock step lose the overlap that the dispatcher's natural skew provides.)
-    const int grp = blockIdx.x;
     const int b0 = grp * G::G;
     AZ_STAMP(0);
     if (tid == 0) any_active = 0;
@@ -410,6 +411,37 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk(DevState d, NetWeights w, 
         }
     }
     AZ_STAMP(5);
+}
+
+template <int N>
+__global__ __launch_bounds__(AZ_NW * 64) void k_trunk(DevState d, NetWeights w, int net_id, float *__restrict__ feat,
+                                               unsigned long long *dbg)
+{
+    typedef NetGeo<N> G;
+    __shared__ __attribute__((aligned(16))) float lds[G::LDSF];
+    __shared__ unsigned short wpos[G::MR];     // centre position of tile cell m in the padded image
+    __shared__ unsigned short cellof[G::MR];   // g*nn + cell index, 0xFFFF for a junk lane
+    __shared__ int any_active;
+    const int ngroups = (d.B + G::G - 1) / G::G;
+#if AZ_SEQ == 0
+    // persistent: one workgroup per CU walks the groups with a grid stride
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        trunk_group<N>(d, w, net_id, feat, dbg, grp, lds, wpos, cellof, &any_active, tid);
+        __syncthreads();
+    }
+#else
+#pragma unroll 1
+    for (int it = 0; it < AZ_SEQ; it++) {
+        const int grp = blockIdx.x * AZ_SEQ + it;
+        if (grp >= ngroups) break;
+        int tid = threadIdx.x;
+        if (AZ_SEQ > 1) asm volatile("" : "+v"(tid));
+        trunk_group<N>(d, w, net_id, feat, dbg, grp, lds, wpos, cellof, &any_active, tid);
+        if (it + 1 < AZ_SEQ) __syncthreads();      // the LDS image is reused by the next group
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
