@@ -577,6 +577,9 @@ static int episode_plies(az_engine *e, int max_steps)
     }
     const int nnets = r.arena ? 2 : 1;
     const LaunchCtx lc = ctx_of_impl(e);
+    // timing-only diagnostics (results are wrong): AZ_DIAG_SKIP=fc | step | fcstep
+    const char *skip = getenv("AZ_DIAG_SKIP");
+    const bool skip_fc = skip && strstr(skip, "fc"), skip_step = skip && strstr(skip, "step");
     auto t0 = std::chrono::steady_clock::now();
     for (int step = 0; step < max_steps && r.active > 0; step++) {
         hipLaunchKernelGGL(k_begin, dim3((d.B + 255) / 256), dim3(256), 0, e->stream, d);
@@ -586,12 +589,12 @@ static int episode_plies(az_engine *e, int max_steps)
                 if (prof) HIPCHECK(e, hipEventRecord(e->ev[ei], e->stream));
                 for (int id = 0; id < nnets; id++) e->ops->trunk(lc, id);
                 if (prof) HIPCHECK(e, hipEventRecord(e->ev[ei + 1], e->stream));
-                for (int id = 0; id < nnets; id++) e->ops->fc(lc, id);
+                if (!skip_fc) for (int id = 0; id < nnets; id++) e->ops->fc(lc, id);
                 if (prof) HIPCHECK(e, hipEventRecord(e->ev[ei + 2], e->stream));
                 r.c.trunk_launches += nnets;
             }
             // t = -1 consumes the root evaluation (root N = 0 for the first selection); t >= 0 consumes simulation t
-            e->ops->step(lc, t + 1, (t + 1 < S) ? 1 : 0);
+            if (!skip_step || t < 0) e->ops->step(lc, t + 1, (t + 1 < S) ? 1 : 0);
             r.c.steps++;
         }
         e->ops->move(lc);

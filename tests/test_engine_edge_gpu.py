@@ -193,3 +193,48 @@ def test_generate_packed_feeds_the_device_replay_ring():
     assert s.shape == (128, 4, 5, 5) and p.shape == (128, 5, 5) and z.shape == (128,)
     assert torch.allclose(p.sum(dim=(1, 2)), torch.ones(128, device=p.device), atol=1e-5)
     assert np.isfinite(ctrl.train_step(s, p, z)["loss"])
+
+
+def test_explicit_tapes_equal_seeded_tapes():
+    """az_selfplay_args.noise_tape / u_tape (host-provided tapes) give the same episode as seed0-generated ones."""
+    n, k, S, G = 5, 4, 30, 4
+    e = _engine(n, k, S, slots=3, synthetic=True)
+    e.selfplay(G, seed0=4000)
+    a = e.records()
+    nn = n * n
+    tapelen = sum(nn - m for m in range(nn))
+    noise = np.zeros((G, tapelen)); us = np.zeros((G, nn))
+    for g in range(G):
+        nz, u = orc.selfplay_tape(4000 + g, n)
+        noise[g], us[g] = nz, u
+    e.selfplay(G, seed0=0, noise_tape=noise, u_tape=us)
+    b = e.records()
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+    e.close()
+
+
+@pytest.mark.parametrize("c_puct,alpha,w", [(1.0, 0.3, 0.25), (4.5, 0.6, 0.4), (2.0, 1.0, 0.1), (0.25, 2.5, 0.9)])
+def test_non_default_search_parameters(c_puct, alpha, w):
+    """mcts.py:87-97 parameters other than the defaults: PUCT constant, Dirichlet alpha (incl. the >= 1 gamma sampler)
+    and mixing weight, engine vs oracle bit for bit, with the engine's own host RNG producing the tape."""
+    n, k, S, G = 9, 5, 50, 3
+    sd = weights_from_fixture(n, "seeded")
+    e = az.Engine(n, k, S, 2, c_puct=c_puct, dirichlet_alpha=alpha, dirichlet_weight=w, log_table=orc.numpy_log_table(S))
+    e.load_weights(sd, 0)
+    e.selfplay(G, seed0=555, max_plies=5)
+    rec = e.records(); nply, _ = e.games()
+    o = orc.Oracle(n, k, S, c_puct=c_puct, alpha=alpha, w=w)
+    onet = orc.Net(n, sd)
+    off = 0
+    for g in range(G):
+        rs = np.random.RandomState(555 + g)
+        nz, us = [], []
+        for m in range(5):
+            nz.append(rs.dirichlet([alpha] * (n * n - m))); us.append(rs.random_sample())
+        r = o.selfplay_game(onet, np.concatenate(nz), np.array(us), maxply=5)
+        L = int(nply[g]); sl = slice(off, off + L)
+        for key in ("actions", "visits", "pis"):
+            assert np.array_equal(rec[key][sl], r[key]), f"{key} differs (c_puct={c_puct}, alpha={alpha}, w={w})"
+        off += L
+    e.close()
