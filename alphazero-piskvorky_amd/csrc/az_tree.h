@@ -356,7 +356,8 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
     }
 }
 
-// numpy pairwise sum of a contiguous float64 block (n <= 128), see oracle for the derivation
+// numpy pairwise sum of a contiguous float64 block (n <= 128): np.add.reduce on a contiguous array accumulates in 8 lanes
+// over blocks of <= 128 and combines them pairwise; probs.sum() at mcts.py:163 goes through it
 __device__ inline double pw_block(const double *a, int n)
 {
     if (n < 8) {
