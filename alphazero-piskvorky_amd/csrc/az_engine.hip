@@ -49,7 +49,8 @@ struct az_engine {
     DevBuf board, s_game, s_ply, s_player, s_last, s_status, s_net, edges, rows_used, path, depth, leaf_kind, leaf,
         leaf_last, logits, vhid, pol_feat, T_table, log_table, sqrt_table, noise_off, cnt, next_game, active;
     // per-episode buffers
-    DevBuf dbg;
+    DevBuf dbg, scratch;
+    int split_max = 32;            // use the split (low-latency) trunk when at most this many slots are active (measured crossover)
     DevBuf noise, u, rec_planes, rec_last, rec_action, rec_mover, rec_pi, rec_visits, g_nply, g_result, src_index;
     int episode_games = 0;
     int64_t tape_len = 0;          // doubles per game in the noise tape
@@ -80,6 +81,7 @@ static LaunchCtx ctx_of_impl(const az_engine *e)
     c.synthetic = e->cfg.eval_kind == AZ_EVAL_SYNTHETIC;
     c.feat = (float *)e->pol_feat.p;
     c.dbg = (unsigned long long *)e->dbg.p;
+    c.scratch = (float *)e->scratch.p;
     return c;
 }
 
@@ -395,6 +397,17 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
     }
     d.v2w[0] = d.v2w[1] = d.v2b[0] = d.v2b[1] = nullptr;
+    if (cfg->model == AZ_MODEL_PLAIN) {
+        const char *sm = getenv("AZ_SPLIT_MAX");      // 0 disables the split trunk, a large value forces it
+        if (sm) e->split_max = atoi(sm);
+        if (e->split_max > 0) {
+            // zeroed once: the padding ring of the packed images is never written afterwards
+            int rc2 = dev_alloc(e, e->scratch, (size_t)e->ops->split_scratch_floats(cfg->slots) * sizeof(float), true);
+            if (rc2) { g_create_error = e->err; az_destroy(e); return rc2; }
+        }
+    } else {
+        e->split_max = 0;
+    }
     const char *pe = getenv("AZ_PROFILE_EVENTS");
     e->profile = !(pe && pe[0] == '0');
     if (hipStreamSynchronize(e->stream) != hipSuccess) {
@@ -414,7 +427,7 @@ extern "C" void az_destroy(az_engine *e)
     DevBuf *all[] = {&e->board, &e->s_game, &e->s_ply, &e->s_player, &e->s_last, &e->s_status, &e->s_net, &e->edges,
                      &e->rows_used, &e->path, &e->depth, &e->leaf_kind, &e->leaf, &e->leaf_last, &e->logits, &e->vhid,
                      &e->pol_feat, &e->T_table, &e->log_table, &e->sqrt_table, &e->noise_off, &e->cnt,
-                     &e->next_game, &e->active, &e->noise, &e->u, &e->rec_planes, &e->rec_last, &e->rec_action,
+                     &e->next_game, &e->active, &e->scratch, &e->noise, &e->u, &e->rec_planes, &e->rec_last, &e->rec_action,
                      &e->rec_mover, &e->rec_pi, &e->rec_visits, &e->g_nply, &e->g_result, &e->src_index};
     for (DevBuf *b : all) dev_free(*b);
     for (int s = 0; s < 2; s++) {
@@ -582,12 +595,13 @@ static int episode_plies(az_engine *e, int max_steps)
     const bool skip_fc = skip && strstr(skip, "fc"), skip_step = skip && strstr(skip, "step");
     auto t0 = std::chrono::steady_clock::now();
     for (int step = 0; step < max_steps && r.active > 0; step++) {
+        const bool use_split = e->split_max > 0 && e->scratch.p && r.active <= e->split_max;   // few pending boards: latency path
         hipLaunchKernelGGL(k_begin, dim3((d.B + 255) / 256), dim3(256), 0, e->stream, d);
         for (int t = -1; t < S; t++) {
             if (net) {
                 const int ei = 3 * (t + 1);
                 if (prof) HIPCHECK(e, hipEventRecord(e->ev[ei], e->stream));
-                for (int id = 0; id < nnets; id++) e->ops->trunk(lc, id);
+                for (int id = 0; id < nnets; id++) { if (use_split) e->ops->trunk_split(lc, id); else e->ops->trunk(lc, id); }
                 if (prof) HIPCHECK(e, hipEventRecord(e->ev[ei + 1], e->stream));
                 if (!skip_fc) for (int id = 0; id < nnets; id++) e->ops->fc(lc, id);
                 if (prof) HIPCHECK(e, hipEventRecord(e->ev[ei + 2], e->stream));
@@ -885,7 +899,7 @@ extern "C" int az_net_eval(az_engine *e, int slot, int count, const uint8_t *boa
         if (hr != hipSuccess) { rc = fail(e, AZ_ERR_HIP, "az_net_eval upload: %s", hipGetErrorString(hr)); break; }
         {
             const LaunchCtx lc = ctx_of_impl(e);
-            e->ops->trunk(lc, slot);
+            if (e->split_max > 0 && e->scratch.p && cnt <= e->split_max) e->ops->trunk_split(lc, slot); else e->ops->trunk(lc, slot);
             e->ops->fc(lc, slot);
             e->ops->eval_tail(lc, cnt, (float *)dpol.p, (float *)dval.p);
         }

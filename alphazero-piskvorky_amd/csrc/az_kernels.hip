@@ -25,6 +25,23 @@ void trunk(const LaunchCtx &c, int net_id)
     }
 }
 
+void trunk_split(const LaunchCtx &c, int net_id)
+{
+    typedef NetGeo<N> G;
+    const int ngroups = (c.d.B + G::G - 1) / G::G;
+    dim3 bt(G::NW * 64);
+    hipLaunchKernelGGL((k_split<N, 1>), dim3(ngroups, 2), bt, 0, c.stream, c.d, c.w[net_id], net_id, c.scratch, c.feat);
+    hipLaunchKernelGGL((k_split<N, 2>), dim3(ngroups, 4), bt, 0, c.stream, c.d, c.w[net_id], net_id, c.scratch, c.feat);
+    hipLaunchKernelGGL((k_split<N, 3>), dim3(ngroups, 8), bt, 0, c.stream, c.d, c.w[net_id], net_id, c.scratch, c.feat);
+    hipLaunchKernelGGL((k_split<N, 4>), dim3(ngroups), bt, 0, c.stream, c.d, c.w[net_id], net_id, c.scratch, c.feat);
+}
+
+long long split_scratch_floats(int slots)
+{
+    typedef NetGeo<N> G;
+    return (long long)((slots + G::G - 1) / G::G) * SplitGeo<N>::PER_GROUP;
+}
+
 void fc(const LaunchCtx &c, int net_id)
 {
     unsigned long long *dbgfc = c.dbg ? c.dbg + (size_t)c.d.B * 16 : nullptr;
@@ -64,6 +81,6 @@ void eval_tail_l(const LaunchCtx &c, int count, float *pol, float *val)
 
 const SizeOps *AZ_CAT(az_size_ops_, AZ_N)()
 {
-    static const SizeOps ops = {trunk, fc, step, move, eval_tail_l};
+    static const SizeOps ops = {trunk, trunk_split, split_scratch_floats, fc, step, move, eval_tail_l};
     return &ops;
 }

@@ -12,10 +12,13 @@ struct LaunchCtx {
     int synthetic;      // AZ_EVAL_SYNTHETIC
     float *feat;
     unsigned long long *dbg;
+    float *scratch;     // split-trunk images, SizeOps::split_floats_per_group floats per board group (or null)
 };
 
 struct SizeOps {
     void (*trunk)(const LaunchCtx &, int net_id);
+    void (*trunk_split)(const LaunchCtx &, int net_id);     // plain net only; same results, lower latency for few boards
+    long long (*split_scratch_floats)(int slots);
     void (*fc)(const LaunchCtx &, int net_id);
     void (*step)(const LaunchCtx &, int rootN, int do_select);
     void (*move)(const LaunchCtx &);

@@ -136,13 +136,15 @@ enum { CONV_OUT_PACKED = 0, CONV_OUT3 = 1, CONV_OUT_RESIDUAL = 2 };   // RESIDUA
 // CIN == 4 (conv1) reads plain planes [ci][pos]; CIN >= 32 reads the packed image above.
 // OUT3=false: relu(acc+bias) -> packed image of the next layer.  OUT3=true (conv3): barrier, then the
 // [co][cell] image that overlays the (now dead) inputs.
-template <class G, int CIN, int COUT, int MODE>
+// NTL / nt_base: the split (low-latency) kernels give one workgroup only NTL of the layer's channel tiles, starting
+// at tile nt_base; the fused kernels use all of them.
+template <class G, int CIN, int COUT, int MODE, int NTL = COUT / 16>
 __device__ __forceinline__ void conv_layer(const float *in, float *out, const float *__restrict__ wp,
                                            const float *__restrict__ bias, const unsigned short *wpos,
-                                           const unsigned short *cellof, int wave, int lane)
+                                           const unsigned short *cellof, int wave, int lane, int nt_base = 0)
 {
     constexpr bool OUT3 = MODE == CONV_OUT3;
-    constexpr int NT = COUT / 16;                              // channel tiles
+    constexpr int NT = NTL;                                    // channel tiles handled by this workgroup
     constexpr int NTW = (AZ_NTW <= NT) ? AZ_NTW : NT;          // channel tiles per wave
     constexpr int NG = NT / NTW;                               // channel-tile groups
     constexpr int MG = (G::NW / NG) > 0 ? (G::NW / NG) : 1;    // cell-tile groups
@@ -161,7 +163,7 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
 
     const float4 *wp4[NTW];
 #pragma unroll
-    for (int t = 0; t < NTW; t++) wp4[t] = reinterpret_cast<const float4 *>(wp) + (size_t)(ng * NTW + t) * KS4 * 64 + lane;
+    for (int t = 0; t < NTW; t++) wp4[t] = reinterpret_cast<const float4 *>(wp) + (size_t)(nt_base + ng * NTW + t) * KS4 * 64 + lane;
     if constexpr (CIN == 4) {
         // conv1: 9 k-steps (one per tap), channels = {mover, opponent, last move, zero plane}, planes [ci][pos]
         int rb[MTW];
@@ -251,7 +253,7 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
     if constexpr (OUT3) __syncthreads();   // every wave has finished reading the conv3 input image
 #pragma unroll
     for (int t = 0; t < NTW; t++) {
-        const int nt = ng * NTW + t;
+        const int nt = nt_base + ng * NTW + t;
         float bco[4];
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) bco[rg] = bias[nt * 16 + q * 4 + rg];
@@ -442,6 +444,140 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk(DevState d, NetWeights w, 
         if (it + 1 < AZ_SEQ) __syncthreads();      // the LDS image is reused by the next group
     }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split trunk (GomokuNet): the low-latency path for launches with few pending boards (episode tails, the arena,
+// single-position search).  The fused k_trunk keeps a board on ONE CU (~95 us of paced MFMAs at n = 15); here every
+// layer is its own launch and a board's channel tiles are spread over 2 / 4 / 8 workgroups, the activations crossing
+// HBM/L2 in the same packed images (scratch per board group, padding ring zeroed once at allocation).  Same fma
+// chains, so the results are bit-identical to k_trunk.
+//   stage 1: encode + conv1   grid (groups, 2)      -> img1  (32 channels, packed)
+//   stage 2: conv2            grid (groups, 4)      -> img2  (64 channels, packed)
+//   stage 3: conv3            grid (groups, 8)      -> img3  ([co][cell], stride CS3)
+//   stage 4: 1x1 heads        grid (groups)         -> feature rows
+// ------------------------------------------------------------------------------------------------
+template <int N>
+struct SplitGeo {
+    typedef NetGeo<N> G;
+    static constexpr int IMG1 = 32 * G::CS, IMG2 = 64 * G::CS, IMG3 = 128 * G::CS3;
+    static constexpr int PER_GROUP = IMG1 + IMG2 + IMG3;      // floats of scratch per board group
+};
+
+template <int N>
+__device__ __forceinline__ bool split_prologue(const DevState &d, int net_id, int b0, unsigned short *wpos,
+                                               unsigned short *cellof, int *any_active, int tid)
+{
+    typedef NetGeo<N> G;
+    if (tid == 0) *any_active = 0;
+    __syncthreads();
+    if (tid < G::G) {
+        int b = b0 + tid;
+        if (b < d.B) {
+            int kind = d.leaf_kind[b];
+            if ((kind == LEAF_ROOT || kind == LEAF_EXPAND) && d.s_status[b] == SLOT_ACTIVE && d.s_net[b] == net_id)
+                atomicOr(any_active, 1);
+        }
+    }
+    for (int m = tid; m < G::MR; m += G::NW * 64) {
+        int pos, cell;
+        if constexpr (G::ROWT) {
+            const int t = m >> 4, c = m & 15, g = t / N, r = t - g * N;
+            pos = g * G::PP + (r + 1) * G::PW + (c + 1);
+            cell = c < N ? g * G::nn + r * N + c : 0xFFFF;
+        } else {
+            const int g = m / G::nn, p = m - g * G::nn, r = p / N, c = p - r * N;
+            pos = m < G::M ? g * G::PP + (r + 1) * G::PW + (c + 1) : G::PW + 1;
+            cell = m < G::M ? m : 0xFFFF;
+        }
+        wpos[m] = (unsigned short)pos;
+        cellof[m] = (unsigned short)cell;
+    }
+    __syncthreads();
+    return *any_active != 0;
+}
+
+template <int N, int STAGE>
+__global__ __launch_bounds__(AZ_NW * 64) void k_split(DevState d, NetWeights w, int net_id, float *__restrict__ scratch,
+                                                      float *__restrict__ feat)
+{
+    typedef NetGeo<N> G;
+    typedef SplitGeo<N> SG;
+    constexpr int NTH = G::NW * 64;
+    constexpr int LDSF = STAGE == 1 ? 4 * G::CS : (STAGE == 2 ? 32 * G::CS : (STAGE == 3 ? 64 * G::CS : 128 * G::CS3));
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+    __shared__ unsigned short wpos[G::MR];
+    __shared__ unsigned short cellof[G::MR];
+    __shared__ int any_active;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = blockIdx.x, b0 = grp * G::G;
+    if (!split_prologue<N>(d, net_id, b0, wpos, cellof, &any_active, tid)) return;
+    float *img1 = scratch + (size_t)grp * SG::PER_GROUP, *img2 = img1 + SG::IMG1, *img3 = img2 + SG::IMG2;
+    if constexpr (STAGE == 1) {
+        for (int i = tid; i < LDSF; i += NTH) lds[i] = 0.0f;
+        __syncthreads();
+        for (int m = tid; m < G::MR; m += NTH) {          // games.py:86-129 encode
+            const int cell = cellof[m];
+            if (cell != 0xFFFF) {
+                const int g = cell / G::nn, p = cell - g * G::nn;
+                const int b = b0 + g;
+                if (b < d.B) {
+                    const u64 *lf = d.leaf + (size_t)b * 8;
+                    const int pos = wpos[m];
+                    if ((lf[p >> 6] >> (p & 63)) & 1ull) lds[pos] = 1.0f;
+                    if ((lf[4 + (p >> 6)] >> (p & 63)) & 1ull) lds[G::CS + pos] = 1.0f;
+                    if (d.leaf_last[b] == p) lds[2 * G::CS + pos] = 1.0f;
+                }
+            }
+        }
+        __syncthreads();
+        conv_layer<G, 4, 32, CONV_OUT_PACKED, 1>(lds, img1, w.c1, w.c1b, wpos, cellof, wave, lane, blockIdx.y);
+    } else if constexpr (STAGE == 2 || STAGE == 3) {
+        const float4 *src = reinterpret_cast<const float4 *>(STAGE == 2 ? img1 : img2);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = tid; i < LDSF / 4; i += NTH) dst[i] = src[i];
+        __syncthreads();
+        if constexpr (STAGE == 2) conv_layer<G, 32, 64, CONV_OUT_PACKED, 1>(lds, img2, w.c2, w.c2b, wpos, cellof, wave, lane, blockIdx.y);
+        else conv_layer<G, 64, 128, CONV_OUT3, 1>(lds, img3, w.c3, w.c3b, wpos, cellof, wave, lane, blockIdx.y);
+    } else {
+        const float4 *src = reinterpret_cast<const float4 *>(img3);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = tid; i < LDSF / 4; i += NTH) dst[i] = src[i];
+        __syncthreads();
+        const int q = lane >> 4, r16 = lane & 15;
+        const float4 *wp4 = reinterpret_cast<const float4 *>(w.hd) + lane;
+        float hb[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) hb[rg] = (q * 4 + rg) < 6 ? w.hdb[q * 4 + rg] : 0.0f;
+        for (int mt = wave; mt < G::MT; mt += G::NW) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float *ip = lds + q * G::CS3 + mt * 16 + r16;
+#pragma unroll
+            for (int s4 = 0; s4 < 8; s4++) {
+                const float4 bq = wp4[s4 * 64];
+                acc = mfma4(bq.x, ip[(s4 * 16 + 0) * G::CS3], acc);
+                acc = mfma4(bq.y, ip[(s4 * 16 + 4) * G::CS3], acc);
+                acc = mfma4(bq.z, ip[(s4 * 16 + 8) * G::CS3], acc);
+                acc = mfma4(bq.w, ip[(s4 * 16 + 12) * G::CS3], acc);
+            }
+            const int cell = cellof[mt * 16 + r16];
+            if (cell != 0xFFFF) {
+                const int g = cell / G::nn, p = cell - g * G::nn;
+                const int b = b0 + g;
+                if (b < d.B && d.s_net[b] == net_id) {
+#pragma unroll
+                    for (int rg = 0; rg < 4; rg++) {
+                        const int j = q * 4 + rg;
+                        if (j < 6) {
+                            float v = acc[rg] + hb[rg];
+                            feat[(size_t)b * G::FROW + j * G::nn + p] = v > 0.0f ? v : 0.0f;
+                        }
+                    }
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

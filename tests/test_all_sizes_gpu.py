@@ -1,5 +1,7 @@
 """Every board size the engine instantiates (3..15, the reference's BOARD_SIZE is a free integer, constants.py:2):
 engine == oracle bit for bit for the plain net, the ResidualBlock net, the synthetic-evaluator tree and whole games."""
+import os
+
 import numpy as np
 import pytest
 
@@ -31,13 +33,18 @@ def test_forward_both_models_bit_exact(n, k):
     for model in ("plain", "resnet"):
         sd = synthetic_state_dict(n) if model == "plain" else synthetic_resnet_state_dict(n)
         onet = orc.Net(n, sd) if model == "plain" else orc.Net(n, resnet_tensors=fold_resnet_state_dict(sd))
-        e = az.Engine(n, k, 4, 9, model=model)
-        e.load_weights(sd, 0)
-        logits, P, v = e.net_eval(boards, players, lasts)
-        for i in range(len(players)):
-            ol, oP, ov = onet.eval(o.encode(boards[i], int(players[i]), int(lasts[i])))
-            assert np.array_equal(logits[i], ol) and np.array_equal(P[i], oP) and v[i] == np.float32(ov), f"{model} n={n} board {i}"
-        e.close()
+        for split in (("0", "1000000") if model == "plain" else ("0",)):      # fused trunk | split trunk (plain net only)
+            os.environ["AZ_SPLIT_MAX"] = split
+            try:
+                e = az.Engine(n, k, 4, 9, model=model)
+            finally:
+                os.environ.pop("AZ_SPLIT_MAX", None)
+            e.load_weights(sd, 0)
+            logits, P, v = e.net_eval(boards, players, lasts)
+            for i in range(len(players)):
+                ol, oP, ov = onet.eval(o.encode(boards[i], int(players[i]), int(lasts[i])))
+                assert np.array_equal(logits[i], ol) and np.array_equal(P[i], oP) and v[i] == np.float32(ov), f"{model} split={split} n={n} board {i}"
+            e.close()
 
 
 @pytest.mark.parametrize("n,k", SIZES)

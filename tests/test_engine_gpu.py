@@ -18,8 +18,24 @@ import alphazero_piskvorky_amd as az
 from alphazero_piskvorky_amd import _capi
 
 
-def _engine(n, k, S, slots=8, synthetic=False):
-    return az.Engine(n, k, S, slots, synthetic=synthetic, log_table=orc.numpy_log_table(S))
+import os
+
+SPLIT_MODES = ["0", "1000000"]     # AZ_SPLIT_MAX: fused trunk only | split (low-latency) trunk forced
+
+
+def _engine(n, k, S, slots=8, synthetic=False, split=None):
+    """split: value of AZ_SPLIT_MAX while the engine is created (None = library default: split when <= 64 boards pend)."""
+    old = os.environ.get("AZ_SPLIT_MAX")
+    if split is not None:
+        os.environ["AZ_SPLIT_MAX"] = split
+    try:
+        return az.Engine(n, k, S, slots, synthetic=synthetic, log_table=orc.numpy_log_table(S))
+    finally:
+        if split is not None:
+            if old is None:
+                os.environ.pop("AZ_SPLIT_MAX", None)
+            else:
+                os.environ["AZ_SPLIT_MAX"] = old
 
 
 @pytest.mark.parametrize("n,k", SIZES)
@@ -78,11 +94,12 @@ def test_synthetic_selfplay_vs_reference_and_oracle(n, k):
     e.close()
 
 
+@pytest.mark.parametrize("split", SPLIT_MODES)
 @pytest.mark.parametrize("n", [5, 9, 15])
-def test_net_forward_vs_oracle_and_torch(n):
+def test_net_forward_vs_oracle_and_torch(n, split):
     z = load(f"net_{n}.npz")
     tags = ["seeded"] + (["ckpt_saved", "ckpt_0802"] if n == 5 else [])
-    e = _engine(n, 5 if n > 5 else 4, 8, slots=32)
+    e = _engine(n, 5 if n > 5 else 4, 8, slots=32, split=split)
     o = orc.Oracle(n, 5, 1)
     for tag in tags:
         sd = weights_from_fixture(n, tag)
@@ -101,11 +118,12 @@ def test_net_forward_vs_oracle_and_torch(n):
     e.close()
 
 
-def test_net_eval_many_boards_all_slots_and_ragged_tail():
+@pytest.mark.parametrize("split", SPLIT_MODES)
+def test_net_eval_many_boards_all_slots_and_ragged_tail(split):
     """More boards than slots, count not a multiple of the workgroup group size: every row equals the oracle."""
     n = 9
     sd = weights_from_fixture(n, "seeded")
-    e = _engine(n, 5, 4, slots=16)
+    e = _engine(n, 5, 4, slots=16, split=split)
     e.load_weights(sd, 0)
     onet = orc.Net(n, sd)
     o = orc.Oracle(n, 5, 1)
@@ -126,12 +144,13 @@ def test_net_eval_many_boards_all_slots_and_ragged_tail():
     e.close()
 
 
+@pytest.mark.parametrize("split", SPLIT_MODES)
 @pytest.mark.parametrize("n,k", SIZES)
-def test_real_net_search_bit_exact_vs_oracle(n, k):
+def test_real_net_search_bit_exact_vs_oracle(n, k, split):
     z = load(f"netgame_{n}x{k}.npz")
     S = int(z["S"])
     sd = weights_from_fixture(n, str(z["weights"]))
-    e = _engine(n, k, S, slots=4)
+    e = _engine(n, k, S, slots=4, split=split)
     e.load_weights(sd, 0)
     o = orc.Oracle(n, k, S)
     onet = orc.Net(n, sd)
@@ -157,12 +176,13 @@ def test_real_net_search_bit_exact_vs_oracle(n, k):
     e.close()
 
 
-def test_real_net_selfplay_games_bit_exact_vs_oracle_5x5():
+@pytest.mark.parametrize("split", SPLIT_MODES)
+def test_real_net_selfplay_games_bit_exact_vs_oracle_5x5(split):
     z = load("netgame_5x4.npz")
     n, k, S, seed0 = 5, 4, int(z["S"]), int(z["seed0"])
     sd = weights_from_fixture(5, "ckpt_saved")
     G = 6
-    e = _engine(n, k, S, slots=4)
+    e = _engine(n, k, S, slots=4, split=split)
     e.load_weights(sd, 0)
     c = e.selfplay(G, seed0=seed0)
     rec = e.records(); nply, res = e.games()
@@ -188,10 +208,11 @@ def test_real_net_selfplay_games_bit_exact_vs_oracle_5x5():
     e.close()
 
 
+@pytest.mark.parametrize("split", SPLIT_MODES)
 @pytest.mark.parametrize("n,k,S,G,cut", [(9, 5, 24, 5, 6), (15, 5, 16, 3, 3)])
-def test_real_net_selfplay_cut_games_vs_oracle(n, k, S, G, cut):
+def test_real_net_selfplay_cut_games_vs_oracle(n, k, S, G, cut, split):
     sd = weights_from_fixture(n, "seeded")
-    e = _engine(n, k, S, slots=3)
+    e = _engine(n, k, S, slots=3, split=split)
     e.load_weights(sd, 0)
     e.selfplay(G, seed0=4242, max_plies=cut)
     rec = e.records(); nply, res = e.games()
@@ -208,11 +229,12 @@ def test_real_net_selfplay_cut_games_vs_oracle(n, k, S, G, cut):
     e.close()
 
 
-def test_arena_vs_oracle_and_reference():
+@pytest.mark.parametrize("split", SPLIT_MODES)
+def test_arena_vs_oracle_and_reference(split):
     z = load("arena_5x4.npz")
     n, k, S, seed0 = int(z["n"]), int(z["k"]), int(z["S"]), int(z["seed0"])
     G = z["actions"].shape[0]
-    e = _engine(n, k, S, slots=4)
+    e = _engine(n, k, S, slots=4, split=split)
     cand, base = weights_from_fixture(n, "ckpt_saved"), weights_from_fixture(n, "ckpt_0802")
     e.load_weights(cand, 0); e.load_weights(base, 1)
     r = e.arena(G, seed0=seed0, temperature_table=orc.arena_T_table(n * n))
