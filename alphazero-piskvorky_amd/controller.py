@@ -91,6 +91,7 @@ class NeuralNetworkController:
 
     def train(self, examples, epochs=1):
         n = self.net.board_size
+        examples = list(examples)                       # sample_batch may hand over the deque itself
         for s, _, _ in examples[:1]:
             if tuple(s.shape) != (4, n, n):
                 raise ValueError(f"example state has shape {tuple(s.shape)}, expected {(4, n, n)}")   # controller.py:136-138

@@ -54,3 +54,21 @@ class DeviceReplayBuffer:
         self.engine.examples_gather(self.ring.data_ptr(), idx.data_ptr(), sym.data_ptr(), b,
                                     1 if self.aug == AZ_AUG_REFERENCE4 else 0, states.data_ptr(), pis.data_ptr(), zs.data_ptr())
         return states, pis, zs
+
+    def export_examples(self):
+        """All examples currently in the ring as the reference's tuples (state CPU tensor, pi ndarray, int z), oldest
+        first -- e.g. to write a reference-compatible buffer.pkl via ReplayBuffer.extend(...).save(path)."""
+        n, aug = self.n, self.aug
+        start = (self.head - self.count) % self.cap
+        order = torch.as_tensor((np.arange(self.count) + start) % self.cap, dtype=torch.int64, device=self.device)
+        idx = order.repeat_interleave(aug)
+        sym = torch.arange(aug, dtype=torch.int32, device=self.device).repeat(self.count)
+        total = self.count * aug
+        states = torch.empty((total, 4, n, n), dtype=torch.float32, device=self.device)
+        pis = torch.empty((total, n, n), dtype=torch.float32, device=self.device)
+        zs = torch.empty(total, dtype=torch.float32, device=self.device)
+        if total:
+            self.engine.examples_gather(self.ring.data_ptr(), idx.data_ptr(), sym.data_ptr(), total,
+                                        1 if aug == AZ_AUG_REFERENCE4 else 0, states.data_ptr(), pis.data_ptr(), zs.data_ptr())
+        states, pis, zs = states.cpu(), pis.cpu().numpy(), zs.cpu().numpy().astype(np.int64)
+        return [(states[i], pis[i], int(zs[i])) for i in range(total)]

@@ -1,4 +1,5 @@
-"""FIFO replay buffer with the reference's surface (replay_buffer.py:14-75): deque(maxlen), random batches."""
+"""FIFO replay buffer with the reference's surface and file format (replay_buffer.py:14-75): a deque(maxlen) of
+(state, pi, z) tuples, pickled as a deque, so buffer.pkl files move between the reference and this package."""
 import pickle
 import random
 from collections import deque
@@ -11,16 +12,22 @@ class ReplayBuffer:
     def __len__(self):
         return len(self.buffer)
 
-    def extend(self, examples):
-        self.buffer.extend(examples)
+    def extend(self, game_examples):
+        self.buffer.extend(game_examples)
 
     def sample_batch(self, batch_size):
-        return random.sample(list(self.buffer), min(batch_size, len(self.buffer)))
+        if len(self.buffer) < batch_size:
+            return self.buffer                       # replay_buffer.py:36-37: everything when there is not enough
+        return random.sample(list(self.buffer), batch_size)
 
-    def save(self, path):
-        with open(path, "wb") as f:
-            pickle.dump(list(self.buffer), f)
+    def all(self):
+        return list(self.buffer)
 
-    def load(self, path):
-        with open(path, "rb") as f:             # only for files this class wrote itself
-            self.buffer.extend(pickle.load(f))
+    def save(self, filename):
+        with open(filename, "wb") as f:
+            pickle.dump(self.buffer, f)
+
+    def load(self, filename):
+        # a pickle executes code from the file: only load buffers written by this class / your own reference run
+        with open(filename, "rb") as f:
+            self.buffer = deque(pickle.load(f), maxlen=self.buffer.maxlen)

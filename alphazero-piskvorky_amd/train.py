@@ -6,8 +6,8 @@ episode structure so that the drop-in can be exercised end to end:
     python -m alphazero_piskvorky_amd.train --episodes 2 --games 64 --sims 50
 """
 import argparse
-import copy
 import os
+import tempfile
 import time
 
 import torch
@@ -17,6 +17,7 @@ from .controller import NeuralNetworkController
 from .evaluator import ModelEvaluator
 from .games import Gomoku
 from .net import GomokuNet
+from .promoter import ModelPromoter
 from .replay_buffer import ReplayBuffer
 from .self_play import SelfPlayManager
 
@@ -27,10 +28,11 @@ def run(episodes, games, sims, eval_games, device="cuda:0", seed=0, model_dir=No
     torch.manual_seed(seed)
     n = C.BOARD_SIZE
     candidate = NeuralNetworkController(GomokuNet(board_size=n), device=device)
-    baseline = NeuralNetworkController(copy.deepcopy(candidate.net), device=device)
+    model_dir = model_dir or tempfile.mkdtemp(prefix="az_models_")
     manager = SelfPlayManager(candidate, device, mcts_params={"num_simulations": sims, "c_puct": C.SELF_PLAY_EXPLORATION_CONSTANT},
                               seed=seed)
     evaluator = ModelEvaluator(game_class=Gomoku, print_games=False, device=device, seed=seed)
+    promoter = ModelPromoter(model_dir, evaluator, lambda: GomokuNet(board_size=n), device, threshold=PROMOTION_THRESHOLD)
     buffer = ReplayBuffer(capacity=C.BUFFER_CAPACITY)
     history = []
     saved_eval_sims = C.NUM_EVAL_SIMULATIONS
@@ -45,13 +47,7 @@ def run(episodes, games, sims, eval_games, device="cuda:0", seed=0, model_dir=No
             for _ in range(C.BATCHES_PER_EPISODE):                                               # train.py:100-104
                 losses.append(candidate.train(buffer.sample_batch(C.BATCH_SIZE), epochs=C.NUM_EPOCHS))
             evaluator.seed = seed + 7 * ep
-            win_rate, metrics = evaluator.evaluate(candidate, baseline, num_games=eval_games)    # promoter.py:38-43
-            promoted = win_rate > PROMOTION_THRESHOLD                                            # promoter.py:47
-            if promoted:
-                baseline.net.load_state_dict(candidate.net.state_dict())
-                if model_dir:
-                    os.makedirs(model_dir, exist_ok=True)
-                    candidate.save(os.path.join(model_dir, f"model_{int(time.time())}_{ep}.pt"))  # promoter.py:48-50
+            win_rate, metrics, promoted = promoter.evaluate_and_maybe_promote(candidate, num_games=eval_games)   # train.py:114-119
             history.append(dict(metrics, episode=ep, examples=len(data), loss=losses[-1].get("loss"),
                                 promoted=promoted, seconds=time.perf_counter() - t0))
             log(f"[train] episode {ep}: {len(data)} examples, loss {losses[-1].get('loss'):.4f}, "

@@ -130,3 +130,32 @@ def test_temperature_schedules_match_reference_values():
     z = load("arena_5x4.npz")
     t = z["temps"][0]
     assert t[0] == evaluator.temperature_schedule(0) and t[1] == evaluator.temperature_schedule(1) and t[2] == t[1]
+
+
+def test_replay_buffer_and_model_loader_file_formats(tmp_path):
+    """Reference file formats: buffer.pkl = pickled deque of tuples (replay_buffer.py:50-71), models/*.pt = state_dict
+    picked by ctime (model_loader.py:43-56)."""
+    import pickle
+    from collections import deque
+    from alphazero_piskvorky_amd.replay_buffer import ReplayBuffer
+    from alphazero_piskvorky_amd.model_loader import ModelLoader
+    buf = ReplayBuffer(capacity=5)
+    ex = [(torch.zeros(4, 5, 5), np.full((5, 5), 1 / 25, np.float32), z) for z in (1, -1, 0, 1, -1, 0, 1)]
+    buf.extend(ex)
+    assert len(buf) == 5 and buf.all()[0][2] == 0                      # FIFO: the two oldest fell out
+    assert buf.sample_batch(10) is buf.buffer and len(buf.sample_batch(3)) == 3
+    path = str(tmp_path / "buffer.pkl")
+    buf.save(path)
+    raw = pickle.load(open(path, "rb"))
+    assert isinstance(raw, deque) and len(raw) == 5
+    other = ReplayBuffer(capacity=4)
+    other.load(path)
+    assert len(other) == 4 and other.all()[-1][2] == 1
+    mdir = str(tmp_path / "models")
+    ml = ModelLoader(mdir, lambda: net.GomokuNet(board_size=5))
+    assert ml.best_path is None
+    m = ml.get_best_model()                                             # writes a random-init checkpoint
+    files = os.listdir(mdir)
+    assert len(files) == 1 and files[0].startswith("model_") and files[0].endswith(".pt")
+    m2 = ModelLoader(mdir, lambda: net.GomokuNet(board_size=5)).get_best_model()
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))

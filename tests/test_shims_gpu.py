@@ -154,4 +154,8 @@ def test_device_replay_ring_matches_host_examples():
     ctrl = _controller("ckpt_saved")
     out = ctrl.train_step(s[:64], p[:64], z[:64])
     assert np.isfinite(out["loss"])
+    # export in the reference's example format, oldest first == the (record, k) order of examples_from_packed
+    ex = buf.export_examples()
+    assert len(ex) == 4 * R and isinstance(ex[0][0], torch.Tensor) and isinstance(ex[0][1], np.ndarray) and isinstance(ex[0][2], int)
+    assert all(torch.equal(ex[i][0], st[i].cpu()) and np.array_equal(ex[i][1], pi[i].cpu().numpy()) and ex[i][2] == int(zz[i]) for i in range(0, 4 * R, 7))
     e.close()
