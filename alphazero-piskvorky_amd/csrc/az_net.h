@@ -49,8 +49,10 @@ __host__ __device__ constexpr int trunk_lds_floats(int n, int g, int chan)
 }
 __host__ __device__ constexpr int pick_boards(int n, int chan, int budget)
 {
+    // powers of two only: 1024 x k games then split into whole rounds of 256 workgroups (3 boards per workgroup left
+    // the last round of a 4096-game 9x9 launch one-third full)
     int g = 1;
-    for (int t = 2; t <= 4; t++)
+    for (int t = 2; t <= 4; t *= 2)
         if (trunk_lds_floats(n, t, chan) <= budget) g = t;
     return g;
 }
@@ -58,7 +60,7 @@ __host__ __device__ constexpr int pick_boards(int n, int chan, int budget)
 template <int N>
 struct NetGeo {
     static constexpr int n = N, nn = N * N, PW = N + 2, PP = PW * PW;
-    static constexpr int G = pick_boards(N, 96, 36500);            // boards per workgroup: 1 at n >= 12, 2 at 10-11, 3 at 8-9, 4 below
+    static constexpr int G = pick_boards(N, 96, 36500);            // boards per workgroup: 1 at n >= 12, 2 at 8-11, 4 below
     static constexpr int M = G * nn;                               // real GEMM columns (board cells)
     // 16-cell MFMA tiles.  n = 15: one tile = one board row + its right padding cell (contiguous in the padded
     // image, so the 16 lanes of a fragment hit 16 consecutive LDS banks); other sizes: 16 consecutive cells.

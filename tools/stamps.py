@@ -11,7 +11,7 @@ e = az.Engine(n, 5 if n > 5 else 4, 8, B)
 e.load_weights(synthetic_state_dict(n), 0)
 e.selfplay_begin(B, seed0=1)
 e.selfplay_step(1)
-G = {15: 1, 9: 3, 5: 4}[n]
+G = {15: 1, 9: 2, 5: 4}[n]
 ng = (B + G - 1) // G
 buf = np.zeros((ng, 16), np.uint64)
 rc = _capi.lib().az_debug_stamps(e.h, buf.ctypes.data_as(C.c_void_p), ng)
