@@ -27,7 +27,7 @@ AZ_MODEL_PLAIN, AZ_MODEL_RESNET = 0, 1
 EXPORTS = [
     "az_create", "az_destroy", "az_last_error", "az_load_weights", "az_load_weights_resnet", "az_net_eval", "az_search", "az_selfplay",
     "az_selfplay_begin", "az_selfplay_step", "az_selfplay_end", "az_selfplay_games", "az_selfplay_records", "az_record_bytes", "az_selfplay_pack", "az_examples_from_packed",
-    "az_examples_gather", "az_arena", "az_rng_selfplay_tape", "az_rng_uniforms", "az_get_counters",
+    "az_examples_gather", "az_arena", "az_rng_selfplay_tape", "az_rng_uniforms", "az_set_profiling", "az_get_counters",
 ]
 
 
@@ -294,6 +294,9 @@ class Engine:
         return dict(wins=res.wins, losses=res.losses, draws=res.draws, total=res.total, win_rate=res.win_rate,
                     results=results, actions=actions, nply=nply)
 
+    def set_profiling(self, on):
+        lib().az_set_profiling(self.h, 1 if on else 0)
+
     def counters(self):
         c = az_counters()
         lib().az_get_counters(self.h, C.byref(c))
@@ -353,9 +356,13 @@ class MultiEngine:
             active, _ = self.selfplay_step(1 << 20)
         return self.selfplay_end()
 
-    def step_one_engine(self, index=0, max_steps=1):
+    def step_one_engine(self, index=0, max_steps=1, profile=False):
         """Plays plies on ONE part while the others are idle (exclusive kernel timing for the roofline)."""
-        return self.parts[index].selfplay_step(max_steps)
+        self.parts[index].set_profiling(profile)
+        try:
+            return self.parts[index].selfplay_step(max_steps)
+        finally:
+            self.parts[index].set_profiling(False)
 
     def games(self):
         outs = [p.games() for i, p in enumerate(self.parts) if self.shares[i]]

@@ -68,7 +68,7 @@ struct az_engine {
     } run;
     // profiling events
     std::vector<hipEvent_t> ev;
-    bool profile = true;
+    bool profile = false;          // HIP events around every trunk / FC launch (az_set_profiling)
 };
 
 static LaunchCtx ctx_of_impl(const az_engine *e)
@@ -409,7 +409,7 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
         e->split_max = 0;
     }
     const char *pe = getenv("AZ_PROFILE_EVENTS");
-    e->profile = !(pe && pe[0] == '0');
+    e->profile = pe && pe[0] == '1';
     if (hipStreamSynchronize(e->stream) != hipSuccess) {
         g_create_error = "stream sync failed in az_create";
         az_destroy(e);
@@ -534,7 +534,7 @@ struct EpisodeSpec {
     int num_games = 0, max_plies = 0;
     bool add_noise = true, arena = false;
     bool preset = false;      // slot 0 already holds a position (az_search); skip the initial refill
-    bool profile = true;
+    bool profile = true;      // this episode may be timed with HIP events (only when az_set_profiling is on)
 };
 
 static int host_threads()
@@ -1040,6 +1040,13 @@ extern "C" int az_examples_gather(az_engine *e, const void *packed_dev, const in
                        states_dev, pis_dev, z_dev);
     HIPCHECK(e, hipStreamSynchronize(e->stream));
     HIPCHECK(e, hipGetLastError());
+    return AZ_OK;
+}
+
+extern "C" int az_set_profiling(az_engine *e, int on)
+{
+    if (!e) return AZ_ERR_INVALID;
+    e->profile = on != 0;
     return AZ_OK;
 }
 

@@ -121,7 +121,7 @@ def main():
     # launches time the kernel alone on the GPU (with several engines the launches of different streams overlap)
     barrier()
     _, k0 = eng.step_one_engine(0, 0)
-    _, k1 = eng.step_one_engine(0, 1)
+    _, k1 = eng.step_one_engine(0, 1, profile=True)
     cal = {key: k1[key] - k0[key] for key in k1}
     barrier()
     _, c0 = eng.selfplay_step(0)

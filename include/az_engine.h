@@ -191,6 +191,10 @@ int az_arena(az_engine *e, const az_arena_args *args, az_arena_result *out, int3
 int az_rng_selfplay_tape(uint64_t seed, int board_size, double alpha, int max_plies, double *noise, double *u);
 int az_rng_uniforms(uint64_t seed, int count, double *u);
 
+/* HIP-event timing of every trunk / FC launch (az_counters.trunk_seconds, nn_seconds, trunk_launches); off by default:
+ * three events per evaluation batch cost a few microseconds of stream time, which matters on small boards. */
+int az_set_profiling(az_engine *e, int on);
+
 int az_get_counters(const az_engine *e, az_counters *out);
 
 #ifdef __cplusplus
