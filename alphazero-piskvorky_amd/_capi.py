@@ -52,7 +52,8 @@ class az_counters(C.Structure):
     _fields_ = [("games", C.c_int64), ("plies", C.c_int64), ("records", C.c_int64), ("simulations", C.c_int64),
                 ("expansions", C.c_int64), ("root_evals", C.c_int64), ("terminal_hits", C.c_int64),
                 ("depth_sum", C.c_int64), ("steps", C.c_int64), ("seconds", C.c_double), ("nn_seconds", C.c_double),
-                ("trunk_seconds", C.c_double), ("trunk_launches", C.c_int64), ("trunk_boards", C.c_int64)]
+                ("trunk_seconds", C.c_double), ("trunk_launches", C.c_int64), ("trunk_boards", C.c_int64),
+                ("step_seconds", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -64,11 +65,18 @@ struct az_engine {
         int num_games = 0, max_plies = 0, active = 0;
         bool add_noise = true, arena = false, preset = false, profile = true;
         az_counters c{};
-        double trunk_ms = 0.0, nn_ms = 0.0;
+        double trunk_ms = 0.0, nn_ms = 0.0, step_ms = 0.0;
     } run;
     // profiling events
     std::vector<hipEvent_t> ev;
     bool profile = false;          // HIP events around every trunk / FC launch (az_set_profiling)
+    // one ply (k_begin, (S+1) x {trunk, fc, step}, k_move) captured once as a hipGraph and replayed every ply:
+    // 3(S+1)+2 launches (6(S+1)+2 with the split trunk) become one submission.  Indexed [split trunk][arena].
+    struct PlyGraph {
+        hipGraphExec_t exec = nullptr;
+        LaunchCtx key{};           // kernel arguments baked into the nodes; any change re-captures
+    } graph[2][2];
+    bool use_graph = true;         // AZ_GRAPH=0: launch kernel by kernel
 };
 
 static LaunchCtx ctx_of_impl(const az_engine *e)
@@ -410,6 +418,8 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
     }
     const char *pe = getenv("AZ_PROFILE_EVENTS");
     e->profile = pe && pe[0] == '1';
+    const char *ge = getenv("AZ_GRAPH");
+    e->use_graph = !(ge && ge[0] == '0');
     if (hipStreamSynchronize(e->stream) != hipSuccess) {
         g_create_error = "stream sync failed in az_create";
         az_destroy(e);
@@ -437,6 +447,8 @@ extern "C" void az_destroy(az_engine *e)
         for (int i = 0; i < 6; i++) { dev_free(p.rblk[i]); dev_free(p.rblkb[i]); }
     }
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+    for (int i = 0; i < 4; i++)
+        if (e->graph[i >> 1][i & 1].exec) (void)hipGraphExecDestroy(e->graph[i >> 1][i & 1].exec);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -573,6 +585,43 @@ static int episode_begin(az_engine *e, const EpisodeSpec &sp)
     return AZ_OK;
 }
 
+// the kernel sequence of one ply: t = -1 consumes the root evaluation (root N = 0 for the first selection),
+// t >= 0 consumes simulation t
+static void launch_ply(az_engine *e, const LaunchCtx &lc, bool use_split, int nnets, bool net)
+{
+    const DevState &d = lc.d;
+    hipLaunchKernelGGL(k_begin, dim3((d.B + 255) / 256), dim3(256), 0, lc.stream, d);
+    for (int t = -1; t < d.S; t++) {
+        if (net) {
+            for (int id = 0; id < nnets; id++) { if (use_split) e->ops->trunk_split(lc, id); else e->ops->trunk(lc, id); }
+            for (int id = 0; id < nnets; id++) e->ops->fc(lc, id);
+        }
+        e->ops->step(lc, t + 1, (t + 1 < d.S) ? 1 : 0);
+    }
+    e->ops->move(lc);
+}
+
+static std::mutex g_capture_mutex;     // engines of one process capture one at a time (instantiate is not cheap, and rare)
+
+// returns the instantiated graph of one ply for these kernel arguments, capturing it on first use
+static int ply_graph(az_engine *e, const LaunchCtx &lc, bool use_split, int nnets, bool net, hipGraphExec_t *out)
+{
+    az_engine::PlyGraph &g = e->graph[use_split ? 1 : 0][nnets - 1];
+    if (g.exec && memcmp(&g.key, &lc, sizeof(LaunchCtx)) == 0) { *out = g.exec; return AZ_OK; }
+    std::lock_guard<std::mutex> lock(g_capture_mutex);
+    if (g.exec) { HIPCHECK(e, hipGraphExecDestroy(g.exec)); g.exec = nullptr; }
+    hipGraph_t graph = nullptr;
+    HIPCHECK(e, hipStreamBeginCapture(lc.stream, hipStreamCaptureModeThreadLocal));
+    launch_ply(e, lc, use_split, nnets, net);
+    HIPCHECK(e, hipStreamEndCapture(lc.stream, &graph));
+    hipError_t rc = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (rc != hipSuccess) { g.exec = nullptr; return fail(e, AZ_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(rc)); }
+    memcpy(&g.key, &lc, sizeof(LaunchCtx));
+    *out = g.exec;
+    return AZ_OK;
+}
+
 // plays up to max_steps plies of every active slot in lock step (one "step" = MCTS.run for each active game)
 static int episode_plies(az_engine *e, int max_steps)
 {
@@ -582,7 +631,7 @@ static int episode_plies(az_engine *e, int max_steps)
     const int S = d.S;
     const bool net = e->cfg.eval_kind == AZ_EVAL_NET;
     const bool prof = net && r.profile && e->profile;
-    const size_t need_ev = prof ? (size_t)3 * (S + 1) : 0;
+    const size_t need_ev = prof ? (size_t)4 * (S + 1) : 0;
     while (e->ev.size() < need_ev) {
         hipEvent_t ev;
         HIPCHECK(e, hipEventCreate(&ev));
@@ -596,10 +645,18 @@ static int episode_plies(az_engine *e, int max_steps)
     auto t0 = std::chrono::steady_clock::now();
     for (int step = 0; step < max_steps && r.active > 0; step++) {
         const bool use_split = e->split_max > 0 && e->scratch.p && r.active <= e->split_max;   // few pending boards: latency path
+        if (e->use_graph && !prof && !skip) {
+            hipGraphExec_t exec = nullptr;
+            int rcg = ply_graph(e, lc, use_split, nnets, net, &exec);
+            if (rcg) return rcg;
+            HIPCHECK(e, hipGraphLaunch(exec, e->stream));
+            if (net) r.c.trunk_launches += (int64_t)nnets * (S + 1);
+            r.c.steps += S + 1;
+        } else {
         hipLaunchKernelGGL(k_begin, dim3((d.B + 255) / 256), dim3(256), 0, e->stream, d);
         for (int t = -1; t < S; t++) {
             if (net) {
-                const int ei = 3 * (t + 1);
+                const int ei = 4 * (t + 1);
                 if (prof) HIPCHECK(e, hipEventRecord(e->ev[ei], e->stream));
                 for (int id = 0; id < nnets; id++) { if (use_split) e->ops->trunk_split(lc, id); else e->ops->trunk(lc, id); }
                 if (prof) HIPCHECK(e, hipEventRecord(e->ev[ei + 1], e->stream));
@@ -609,9 +666,11 @@ static int episode_plies(az_engine *e, int max_steps)
             }
             // t = -1 consumes the root evaluation (root N = 0 for the first selection); t >= 0 consumes simulation t
             if (!skip_step || t < 0) e->ops->step(lc, t + 1, (t + 1 < S) ? 1 : 0);
+            if (prof) HIPCHECK(e, hipEventRecord(e->ev[4 * (t + 1) + 3], e->stream));
             r.c.steps++;
         }
         e->ops->move(lc);
+        }
         r.c.plies += r.active;
         if (r.preset) {
             r.active = 0;
@@ -623,11 +682,13 @@ static int episode_plies(az_engine *e, int max_steps)
         HIPCHECK(e, hipGetLastError());
         if (prof) {
             for (int i = 0; i <= S; i++) {
-                float a = 0.f, b = 0.f;
-                HIPCHECK(e, hipEventElapsedTime(&a, e->ev[3 * i], e->ev[3 * i + 1]));
-                HIPCHECK(e, hipEventElapsedTime(&b, e->ev[3 * i + 1], e->ev[3 * i + 2]));
+                float a = 0.f, b = 0.f, c = 0.f;
+                HIPCHECK(e, hipEventElapsedTime(&a, e->ev[4 * i], e->ev[4 * i + 1]));
+                HIPCHECK(e, hipEventElapsedTime(&b, e->ev[4 * i + 1], e->ev[4 * i + 2]));
+                HIPCHECK(e, hipEventElapsedTime(&c, e->ev[4 * i + 2], e->ev[4 * i + 3]));
                 r.trunk_ms += a;
                 r.nn_ms += a + b;
+                r.step_ms += c;
             }
         }
     }
@@ -650,6 +711,7 @@ static int read_counters(az_engine *e, az_counters &c)
     }
     c.trunk_seconds = e->run.trunk_ms * 1e-3;
     c.nn_seconds = e->run.nn_ms * 1e-3;
+    c.step_seconds = e->run.step_ms * 1e-3;
     c.root_evals = c.plies;
     c.records = c.plies;
     c.trunk_boards = c.expansions + c.root_evals;

@@ -186,6 +186,35 @@ def main():
             traffic_src = "profiles/r01_pmc_summary.json (separate --pmc passes, per board x boards per launch)"
         except Exception:
             pass
+        # the rest of the path, priced against HBM with SURVEY 8(d)'s algorithmic bytes (reference semantics, fp32 edges):
+        # per simulation  d*(12A+16) [P,N,W of A children per descended level + backup RMW] + 12A [expand]
+        # + 2*ceil(n^2/8)+2 [leaf board] + 4n^2+4 [logits+value read]; A = legal cells at the calibration ply
+        nn_cells = n * n
+        ply_index = a.warmup                                  # plies already played when the calibration ply starts
+        A = nn_cells - ply_index
+        games_cal = max(cal["plies"], 1)                      # games the calibrating engine holds (one ply each)
+        dbar = cal["depth_sum"] / max(cal["simulations"], 1)
+        step_launches = max(cal["steps"], 1)
+        bytes_sim = dbar * (12 * A + 16) + 12 * A + (2 * ((nn_cells + 7) // 8) + 2) + (4 * nn_cells + 4)
+        step_ms = cal["step_seconds"] * 1e3 / step_launches
+        step_gbs = games_cal * bytes_sim / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
+        # k_fc: the three FC layers; bytes = FC weights once per launch + per board (6n^2 head features in, n^2 logits + value out)
+        fc_w_bytes = 4 * (4 * nn_cells * nn_cells + nn_cells + 2 * nn_cells * 64 + 64 + 64 + 1) if a.model == "plain" \
+            else 4 * (2 * nn_cells * nn_cells + nn_cells + nn_cells * 64 + 64 + 64 + 1)
+        feat_in = (6 if a.model == "plain" else 3) * nn_cells * 4
+        fc_ms = (cal["nn_seconds"] - cal["trunk_seconds"]) * 1e3 / launches
+        fc_bytes = fc_w_bytes + (boards / launches) * (feat_in + 4 * nn_cells + 4)
+        fc_gbs = fc_bytes / (fc_ms * 1e-3) / 1e9 if fc_ms > 0 else 0.0
+        rest = [
+            {"kernel": f"k_step<{n}> (softmax/value tail, backup, PUCT select, expand; one wavefront per game)", "bound": "hbm",
+             "achieved": step_gbs, "peak": 8000.0, "unit": "GB/s", "frac": step_gbs / 8000.0, "avg_launch_ms": step_ms,
+             "games_per_launch": games_cal, "bytes_per_simulation": bytes_sim, "mean_select_depth": dbar,
+             "note": "latency-bound: a serial select->backup chain per game, ~2 MB per 256-game launch; runs underneath another engine's trunk"},
+            {"kernel": f"k_fc (policy_fc, value_fc1, value_fc2 on 16-board tiles)", "bound": "hbm",
+             "achieved": fc_gbs, "peak": 8000.0, "unit": "GB/s", "frac": fc_gbs / 8000.0, "avg_launch_ms": fc_ms,
+             "bytes_per_launch": fc_bytes,
+             "note": "FC weights are re-read per 16-board tile from L2; ~1% of the net's FLOPs"},
+        ]
         out = {
             "metric": "mcts_node_expansions_per_sec", "value": exp_all / dt, "unit": "node-expansions/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / max(a.steps, 1),
@@ -205,6 +234,7 @@ def main():
                          "flops_per_board": trunk_f,
                          "measured": "HIP events around every k_trunk launch of one calibration ply played by a single engine "
                                      "(other engines idle), between warmup and the timed region",
+                         "rest": rest,
                          "aggregate": {"achieved": agg, "frac": agg / peak, "unit": "TFLOP/s",
                                        "what": "trunk FLOPs per wall second over the timed region, all engines/streams overlapping "
                                                "(includes the time the FC and tree kernels take)"}},

@@ -130,6 +130,7 @@ typedef struct {
     double trunk_seconds;               /* ... of which the fused conv trunk (dominant kernel)           */
     int64_t trunk_launches;
     int64_t trunk_boards;               /* boards evaluated by the trunk kernel (all launches)           */
+    double step_seconds;                /* HIP-event time inside the tree kernel k_step (select/expand/backup) */
 } az_counters;
 
 int az_selfplay(az_engine *e, const az_selfplay_args *args, az_counters *out);
@@ -191,8 +192,8 @@ int az_arena(az_engine *e, const az_arena_args *args, az_arena_result *out, int3
 int az_rng_selfplay_tape(uint64_t seed, int board_size, double alpha, int max_plies, double *noise, double *u);
 int az_rng_uniforms(uint64_t seed, int count, double *u);
 
-/* HIP-event timing of every trunk / FC launch (az_counters.trunk_seconds, nn_seconds, trunk_launches); off by default:
- * three events per evaluation batch cost a few microseconds of stream time, which matters on small boards. */
+/* HIP-event timing of every trunk / FC / tree-step launch (az_counters.trunk_seconds, nn_seconds, step_seconds);
+ * off by default: four events per evaluation batch cost a few microseconds of stream time, which matters on small boards. */
 int az_set_profiling(az_engine *e, int on);
 
 int az_get_counters(const az_engine *e, az_counters *out);
