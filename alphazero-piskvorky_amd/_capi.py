@@ -270,15 +270,26 @@ class Engine:
                     "az_selfplay_records")
         return out
 
+    @staticmethod
+    def _torch_sync():
+        """The engine works on its own non-blocking HIP stream and synchronises it before every call returns; device
+        buffers handed in by the caller (torch tensors) must be complete on the caller's side too."""
+        import torch
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.current_stream().synchronize()
+
     def pack_into(self, dev_ptr):
+        self._torch_sync()
         self._check(lib().az_selfplay_pack(self.h, C.c_void_p(dev_ptr)), "az_selfplay_pack")
 
     def examples_from_packed(self, packed_ptr, records, aug, states_ptr, pis_ptr, z_ptr):
+        self._torch_sync()
         self._check(lib().az_examples_from_packed(self.h, C.c_void_p(packed_ptr), C.c_int64(records), int(aug),
                                                   C.c_void_p(states_ptr), C.c_void_p(pis_ptr), C.c_void_p(z_ptr)),
                     "az_examples_from_packed")
 
     def examples_gather(self, packed_ptr, idx_ptr, sym_ptr, count, reference_pi, states_ptr, pis_ptr, z_ptr):
+        self._torch_sync()
         self._check(lib().az_examples_gather(self.h, C.c_void_p(packed_ptr), C.c_void_p(idx_ptr), C.c_void_p(sym_ptr),
                                              int(count), int(reference_pi), C.c_void_p(states_ptr), C.c_void_p(pis_ptr),
                                              C.c_void_p(z_ptr)), "az_examples_gather")

@@ -142,6 +142,34 @@ void selfplay_tape(uint64_t seed, int nn, double alpha, int max_plies, double *n
     }
 }
 
+// Resumable per-game streams: the same tapes, produced a few plies at a time while the device plays
+// (the engine's tape producer).  Game i is RandomState(seed0 + i); plies must be requested in order.
+struct Streams {
+    std::vector<MT> mt;
+};
+
+Streams *streams_new(uint64_t seed0, int count)
+{
+    Streams *s = new Streams();
+    s->mt.reserve((size_t)count);
+    for (int i = 0; i < count; i++) s->mt.emplace_back((uint32_t)((seed0 + (uint64_t)i) & 0xffffffffu));
+    return s;
+}
+
+void streams_free(Streams *s) { delete s; }
+
+// plies [m0, m1) of game i: noise_row receives sum_{m} (nn - m) doubles back to back, u_row one double per ply
+void streams_plies(Streams *s, int i, int nn, double alpha, int m0, int m1, double *noise_row, double *u_row)
+{
+    MT &mt = s->mt[(size_t)i];
+    size_t off = 0;
+    for (int m = m0; m < m1; m++) {
+        mt.dirichlet(alpha, nn - m, noise_row + off);
+        off += (size_t)(nn - m);
+        u_row[m - m0] = mt.next_double();
+    }
+}
+
 void uniforms(uint64_t seed, int count, double *u)
 {
     MT mt((uint32_t)(seed & 0xffffffffu));
