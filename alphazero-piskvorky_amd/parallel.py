@@ -47,3 +47,36 @@ def gather_packed_records(engine, device):
     parts, counts = all_gather_packed(packed.cpu() if host_xchg else packed, count, engine.record_bytes)
     out = torch.cat(parts) if len(parts) > 1 else parts[0]
     return (out.to(device) if host_xchg else out), counts
+
+
+def arena_block(num_games, rank, world):
+    """Contiguous block [lo, hi) of arena game indices for this rank.  Blocks start at EVEN indices so a rank's local
+    game parity equals the global one (odd game index => the baseline moves first, evaluator.py:64-69) and its
+    per-game seeds are seed0 + global index with a plain offset."""
+    per = (num_games + world - 1) // world
+    per += per & 1
+    lo = min(rank * per, num_games)
+    return lo, min(lo + per, num_games)
+
+
+def all_reduce_tally(wins, losses, draws, device):
+    """Arena tally exchange: sum of three integers over the ranks (RCCL with an nccl group, gloo otherwise)."""
+    import torch.distributed as td
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return int(wins), int(losses), int(draws)
+    on_dev = td.get_backend() == "nccl"
+    t = torch.tensor([wins, losses, draws], dtype=torch.int64, device=device if on_dev else "cpu")
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    w, l, d = (int(x) for x in t.tolist())
+    return w, l, d
+
+
+def broadcast_seed(seed, device):
+    """Rank 0's seed for everybody (the reference is unseeded; ranks must still agree on the episode's game seeds)."""
+    import torch.distributed as td
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return int(seed)
+    on_dev = td.get_backend() == "nccl"
+    t = torch.tensor([int(seed)], dtype=torch.int64, device=device if on_dev else "cpu")
+    td.broadcast(t, 0)
+    return int(t.item())

@@ -74,10 +74,8 @@ class SelfPlayManager:
         lo, hi = min(rank * per, num_games), min((rank + 1) * per, num_games)
         mine = hi - lo
         seed0 = self.seed if self.seed is not None else int(np.random.randint(0, 2 ** 31 - 1))
-        if world > 1 and self.seed is None:
-            s = torch.tensor([seed0], dtype=torch.int64, device=torch.device("cuda", device_index(self.device)))
-            td.broadcast(s, 0)
-            seed0 = int(s.item())
+        if self.seed is None:
+            seed0 = parallel.broadcast_seed(seed0, torch.device("cuda", device_index(self.device)))
         dev = torch.device("cuda", device_index(self.device))
         eng = self._eng(n, k, max(1, min(self.concurrent_games, max(mine, 1))))
         eng.load_weights(self.controller.net.state_dict(), 0)

@@ -50,3 +50,45 @@ def test_selfplay_manager_two_ranks_equals_single_process(tmp_path):
         assert got["z"].shape == ref["z"].shape and len(ref["z"]) > 0
         for key in ("s", "p", "z"):
             assert np.array_equal(got[key], ref[key]), f"rank {rank}: {key} differs from the single-process episode"
+
+
+ARENA_WORKER = r'''
+import os, sys, json, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as td
+world = int(os.environ.get("WORLD_SIZE", "1"))
+if world > 1:
+    td.init_process_group("gloo")
+from alphazero_piskvorky_amd import net, constants as C
+from alphazero_piskvorky_amd.controller import NeuralNetworkController
+from alphazero_piskvorky_amd.evaluator import ModelEvaluator
+from alphazero_piskvorky_amd.weights import synthetic_state_dict
+C.NUM_EVAL_SIMULATIONS = 24
+def ctrl(seed):
+    m = net.GomokuNet(board_size=5)
+    m.load_state_dict({k: torch.tensor(v) for k, v in synthetic_state_dict(5, seed=seed).items()})
+    return NeuralNetworkController(m, device="cuda:0")
+wr, metrics = ModelEvaluator(None, False, "cuda:0", seed=77).evaluate(ctrl(1234), ctrl(99), num_games=11)
+rank = td.get_rank() if world > 1 else 0
+json.dump(dict(metrics, wr=wr), open(sys.argv[2] + f".{rank}.json", "w"))
+if world > 1:
+    td.barrier(); td.destroy_process_group()
+'''
+
+
+def test_arena_two_ranks_equals_single_process(tmp_path):
+    """Arena games split over two ranks in even-aligned blocks + all-reduced tally == the single-process arena."""
+    import json
+    script = tmp_path / "arena_worker.py"
+    script.write_text(ARENA_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    single = str(tmp_path / "single")
+    subprocess.run([sys.executable, str(script), ROOT, single], check=True, env=env, timeout=300, stdout=subprocess.DEVNULL)
+    multi = str(tmp_path / "multi")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                    "--master-addr", "127.0.0.1", "--master-port", "29735", str(script), ROOT, multi],
+                   check=True, env=env, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    ref = json.load(open(single + ".0.json"))
+    assert ref["total"] == 11
+    for rank in (0, 1):
+        assert json.load(open(multi + f".{rank}.json")) == ref

@@ -62,3 +62,44 @@ def test_single_process_gather_is_identity():
     packed, counts = parallel.gather_packed_records(eng, torch.device("cpu"))
     assert counts == [6] and np.array_equal(packed.numpy(), eng.payload())
     assert parallel.shard_games(10, 1, 4) == [1, 5, 9]
+
+
+def _tally_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from alphazero_piskvorky_amd import parallel
+    tally = parallel.all_reduce_tally(3 + rank, 1, 2 * rank, torch.device("cpu"))
+    seed = parallel.broadcast_seed(1000 + 77 * rank, torch.device("cpu"))
+    q.put((rank, tally, seed))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_arena_tally_and_seed_world2_gloo():
+    """the arena's only exchange is the sum of (wins, losses, draws); every rank plays with rank 0's seed."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_tally_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, tally, seed in outs:
+        assert tuple(tally) == (7, 2, 2) and seed == 1000
+
+
+def test_arena_blocks_are_even_aligned_and_cover_all_games():
+    from alphazero_piskvorky_amd import parallel
+    for games in (1, 2, 7, 20, 51, 64):
+        for world in (1, 2, 3, 8):
+            blocks = [parallel.arena_block(games, r, world) for r in range(world)]
+            assert all(lo % 2 == 0 or lo == hi for lo, hi in blocks)       # local parity == global parity (evaluator.py:64-69)
+            covered = [g for lo, hi in blocks for g in range(lo, hi)]
+            assert covered == list(range(games))
+    assert parallel.all_reduce_tally(4, 5, 6, torch.device("cpu")) == (4, 5, 6)     # no process group: identity
+    assert parallel.broadcast_seed(99, torch.device("cpu")) == 99
