@@ -238,3 +238,28 @@ def test_non_default_search_parameters(c_puct, alpha, w):
             assert np.array_equal(rec[key][sl], r[key]), f"{key} differs (c_puct={c_puct}, alpha={alpha}, w={w})"
         off += L
     e.close()
+
+
+def test_streamed_tapes_equal_bulk_tapes_with_refill_and_restart(monkeypatch):
+    """The tape producer (waves of two plies streamed ahead of the games) against AZ_TAPE_STREAM=0 (every tape generated
+    before the first move): many more games than slots, so refilled slots start late at ply 0 while the waves are far
+    ahead; also an episode abandoned mid-way (its producer must stop) and a max_plies cap shorter than one wave."""
+    n, k, S, G = 5, 4, 12, 37
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("AZ_TAPE_STREAM", mode)
+        e = _engine(n, k, S, slots=5, synthetic=True)
+        e.selfplay_begin(G, seed0=31337)
+        e.selfplay_step(3)                      # abandoned: the next begin replaces the episode and its producer
+        e.selfplay(G, seed0=31337)
+        full = e.records(); nply, res = e.games()
+        e.selfplay(G, seed0=31337, max_plies=1)
+        capped = e.records()
+        out[mode] = (full, nply, res, capped)
+        e.close()
+    for a, b in zip(out["1"][0].values(), out["0"][0].values()):
+        assert np.array_equal(a, b)
+    assert np.array_equal(out["1"][1], out["0"][1]) and np.array_equal(out["1"][2], out["0"][2])
+    for key in out["1"][3]:
+        assert np.array_equal(out["1"][3][key], out["0"][3][key]), key
+    assert len(out["1"][3]["actions"]) == G
