@@ -47,6 +47,9 @@ __host__ __device__ constexpr int trunk_lds_floats(int n, int g, int chan)
     const int a = chan * cs, b = chan == 96 ? 128 * up16(mr) : 0;     // plain net: the conv3 image overlays the inputs
     return a > b ? a : b;
 }
+#ifndef AZ_G_BUDGET
+#define AZ_G_BUDGET 36500      // LDS floats the packed images of one trunk workgroup may take (146 KB)
+#endif
 __host__ __device__ constexpr int pick_boards(int n, int chan, int budget)
 {
     // powers of two only: 1024 x k games then split into whole rounds of 256 workgroups (3 boards per workgroup left
@@ -60,7 +63,7 @@ __host__ __device__ constexpr int pick_boards(int n, int chan, int budget)
 template <int N>
 struct NetGeo {
     static constexpr int n = N, nn = N * N, PW = N + 2, PP = PW * PW;
-    static constexpr int G = pick_boards(N, 96, 36500);            // boards per workgroup: 1 at n >= 12, 2 at 8-11, 4 below
+    static constexpr int G = pick_boards(N, 96, AZ_G_BUDGET);            // boards per workgroup: 1 at n >= 12, 2 at 8-11, 4 below
     static constexpr int M = G * nn;                               // real GEMM columns (board cells)
     // 16-cell MFMA tiles.  n = 15: one tile = one board row + its right padding cell (contiguous in the padded
     // image, so the 16 lanes of a fragment hit 16 consecutive LDS banks); other sizes: 16 consecutive cells.
