@@ -80,3 +80,22 @@ def broadcast_seed(seed, device):
     t = torch.tensor([int(seed)], dtype=torch.int64, device=device if on_dev else "cpu")
     td.broadcast(t, 0)
     return int(t.item())
+
+
+def broadcast_module_(module, src=0):
+    """Rank `src`'s parameters and buffers for everybody, in place (the weight exchange after the optimizer
+    steps, so that every rank searches with the same net in the next episode).  RCCL moves the device tensors directly;
+    with a gloo group they are staged through the host."""
+    import torch.distributed as td
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return module
+    direct = td.get_backend() == "nccl"
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            if direct or t.device.type == "cpu":
+                td.broadcast(t.data, src)
+            else:
+                h = t.data.cpu()
+                td.broadcast(h, src)
+                t.data.copy_(h)
+    return module

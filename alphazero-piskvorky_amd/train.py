@@ -13,6 +13,7 @@ import time
 import torch
 
 from . import constants as C
+from . import parallel
 from .controller import NeuralNetworkController
 from .evaluator import ModelEvaluator
 from .games import Gomoku
@@ -46,6 +47,7 @@ def run(episodes, games, sims, eval_games, device="cuda:0", seed=0, model_dir=No
             losses = []
             for _ in range(C.BATCHES_PER_EPISODE):                                               # train.py:100-104
                 losses.append(candidate.train(buffer.sample_batch(C.BATCH_SIZE), epochs=C.NUM_EPOCHS))
+            parallel.broadcast_module_(candidate.net)          # multi-rank: everybody continues with rank 0's weights
             evaluator.seed = seed + 7 * ep
             win_rate, metrics, promoted = promoter.evaluate_and_maybe_promote(candidate, num_games=eval_games)   # train.py:114-119
             history.append(dict(metrics, episode=ep, examples=len(data), loss=losses[-1].get("loss"),
@@ -67,7 +69,21 @@ def main():
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--model-dir", default=None)
     a = ap.parse_args()
+    # one process per GPU under torch.distributed.run: games and arena games are sharded over the ranks (self_play.py,
+    # evaluator.py), the examples are all-gathered, every rank takes the same optimizer steps' result from rank 0
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as td
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+        a.device = f"cuda:{local}"
+        if td.get_rank() != 0 and a.model_dir is None:
+            a.model_dir = tempfile.mkdtemp(prefix=f"az_models_rank{td.get_rank()}_")
     run(a.episodes, a.games, a.sims, a.eval_games, a.device, model_dir=a.model_dir)
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
 
 
 if __name__ == "__main__":

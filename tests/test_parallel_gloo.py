@@ -103,3 +103,37 @@ def test_arena_blocks_are_even_aligned_and_cover_all_games():
             assert covered == list(range(games))
     assert parallel.all_reduce_tally(4, 5, 6, torch.device("cpu")) == (4, 5, 6)     # no process group: identity
     assert parallel.broadcast_seed(99, torch.device("cpu")) == 99
+
+
+def _bcast_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from alphazero_piskvorky_amd import parallel
+    from alphazero_piskvorky_amd.net import GomokuResNet
+    torch.manual_seed(100 + rank)                     # different weights and BatchNorm statistics on every rank
+    net = GomokuResNet(board_size=5)
+    net.bn.running_mean.add_(rank + 1.0)
+    parallel.broadcast_module_(net, src=0)
+    q.put((rank, {k: v.numpy().copy() for k, v in net.state_dict().items()}))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_weight_broadcast_world2_gloo():
+    """After the optimizer steps every rank continues with rank 0's parameters and buffers."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict((r, sd) for r, sd in (q.get(timeout=120) for _ in range(2)))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert set(outs[0]) == set(outs[1]) and len(outs[0]) > 20
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert float(outs[1]["bn.running_mean"][0]) == 1.0          # rank 0's buffer (0 + 1), not rank 1's
