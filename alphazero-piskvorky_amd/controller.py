@@ -107,6 +107,26 @@ class NeuralNetworkController:
         self.net.eval()
         return self.training_history[-1] if self.training_history else {}
 
+    def train_tensors(self, states, pis, zs, epochs=1):
+        """train() for a batch that is already on the device as tensors (device_replay.DeviceReplayBuffer.sample_batch):
+        the same epochs of shuffled mini-batches of `batch_size` (controller.py:140-194), no Dataset / DataLoader hop."""
+        n = self.net.board_size
+        if tuple(states.shape[1:]) != (4, n, n):
+            raise ValueError(f"example state has shape {tuple(states.shape[1:])}, expected {(4, n, n)}")
+        total = states.shape[0]
+        for _ in range(epochs):
+            perm = torch.randperm(total, device=states.device)
+            sums, batches = {}, 0
+            for lo in range(0, total, self.batch_size):
+                idx = perm[lo:lo + self.batch_size]
+                out = self.train_step(states[idx], pis[idx], zs[idx])
+                for k, v in out.items():
+                    sums[k] = sums.get(k, 0.0) + v
+                batches += 1
+            self.training_history.append({k: v / max(batches, 1) for k, v in sums.items()})
+        self.net.eval()
+        return self.training_history[-1] if self.training_history else {}
+
     def save(self, path):
         torch.save(self.net.state_dict(), path)
 

@@ -25,7 +25,9 @@ from .self_play import SelfPlayManager
 PROMOTION_THRESHOLD = 0.55          # promoter.py:19, strict ">" with draws counted one half
 
 
-def run(episodes, games, sims, eval_games, device="cuda:0", seed=0, model_dir=None, log=print):
+def run(episodes, games, sims, eval_games, device="cuda:0", seed=0, model_dir=None, log=print, device_replay=False):
+    """device_replay=True keeps the examples on the GPU from the episode-end gather to the optimizer step (packed records
+    in a device ring, batches unpacked + augmented by az_examples_gather) instead of materialising Python tuples."""
     torch.manual_seed(seed)
     n = C.BOARD_SIZE
     candidate = NeuralNetworkController(GomokuNet(board_size=n), device=device)
@@ -35,6 +37,7 @@ def run(episodes, games, sims, eval_games, device="cuda:0", seed=0, model_dir=No
     evaluator = ModelEvaluator(game_class=Gomoku, print_games=False, device=device, seed=seed)
     promoter = ModelPromoter(model_dir, evaluator, lambda: GomokuNet(board_size=n), device, threshold=PROMOTION_THRESHOLD)
     buffer = ReplayBuffer(capacity=C.BUFFER_CAPACITY)
+    ring = None
     history = []
     saved_eval_sims = C.NUM_EVAL_SIMULATIONS
     C.NUM_EVAL_SIMULATIONS = sims
@@ -42,11 +45,21 @@ def run(episodes, games, sims, eval_games, device="cuda:0", seed=0, model_dir=No
         for ep in range(episodes):
             t0 = time.perf_counter()
             manager.seed = seed + 1_000_003 * ep
-            data = manager.generate_self_play(num_games=games, num_workers=C.NUM_WORKERS)       # train.py:89-92
-            buffer.extend(data)                                                                  # train.py:95
             losses = []
-            for _ in range(C.BATCHES_PER_EPISODE):                                               # train.py:100-104
-                losses.append(candidate.train(buffer.sample_batch(C.BATCH_SIZE), epochs=C.NUM_EPOCHS))
+            if device_replay:
+                from .device_replay import DeviceReplayBuffer
+                packed, records, eng, dev, _ = manager.generate_packed(games)
+                if ring is None:
+                    ring = DeviceReplayBuffer(eng, capacity=C.BUFFER_CAPACITY, aug=manager.augmentation, device=dev, seed=seed)
+                ring.extend_packed(packed, records)
+                data = range(records * manager.augmentation)
+                for _ in range(C.BATCHES_PER_EPISODE):
+                    losses.append(candidate.train_tensors(*ring.sample_batch(C.BATCH_SIZE), epochs=C.NUM_EPOCHS))
+            else:
+                data = manager.generate_self_play(num_games=games, num_workers=C.NUM_WORKERS)   # train.py:89-92
+                buffer.extend(data)                                                              # train.py:95
+                for _ in range(C.BATCHES_PER_EPISODE):                                           # train.py:100-104
+                    losses.append(candidate.train(buffer.sample_batch(C.BATCH_SIZE), epochs=C.NUM_EPOCHS))
             parallel.broadcast_module_(candidate.net)          # multi-rank: everybody continues with rank 0's weights
             evaluator.seed = seed + 7 * ep
             win_rate, metrics, promoted = promoter.evaluate_and_maybe_promote(candidate, num_games=eval_games)   # train.py:114-119
@@ -68,6 +81,7 @@ def main():
     ap.add_argument("--eval-games", type=int, default=C.EVALUATION_GAMES)
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--model-dir", default=None)
+    ap.add_argument("--device-replay", action="store_true", help="keep examples on the GPU (packed ring + on-device batch unpacking)")
     a = ap.parse_args()
     # one process per GPU under torch.distributed.run: games and arena games are sharded over the ranks (self_play.py,
     # evaluator.py), the examples are all-gathered, every rank takes the same optimizer steps' result from rank 0
@@ -80,7 +94,7 @@ def main():
         a.device = f"cuda:{local}"
         if td.get_rank() != 0 and a.model_dir is None:
             a.model_dir = tempfile.mkdtemp(prefix=f"az_models_rank{td.get_rank()}_")
-    run(a.episodes, a.games, a.sims, a.eval_games, a.device, model_dir=a.model_dir)
+    run(a.episodes, a.games, a.sims, a.eval_games, a.device, model_dir=a.model_dir, device_replay=a.device_replay)
     if world > 1:
         td.barrier()
         td.destroy_process_group()

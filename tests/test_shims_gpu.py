@@ -108,13 +108,16 @@ def test_mcts_rejects_python_callables():
         MCTS(lambda s: (None, 0.0), num_simulations=10, c_puct=2.0)
 
 
-def test_training_loop_plumbing_config1():
-    """BASELINE.json configs[0] plumbing on the GPU path: self-play -> buffer -> AdamW -> arena -> promote (train.py:85-119)."""
+@pytest.mark.parametrize("device_replay", [False, True])
+def test_training_loop_plumbing_config1(device_replay):
+    """BASELINE.json configs[0] plumbing on the GPU path: self-play -> buffer -> AdamW -> arena -> promote (train.py:85-119);
+    device_replay=True keeps the examples in the device ring instead of Python tuples."""
     from alphazero_piskvorky_amd import train
     saved = (constants.BATCHES_PER_EPISODE, constants.NUM_EPOCHS, constants.BATCH_SIZE)
     constants.BATCHES_PER_EPISODE, constants.NUM_EPOCHS, constants.BATCH_SIZE = 2, 1, 256
     try:
-        hist = train.run(episodes=2, games=16, sims=24, eval_games=6, device="cuda:0", seed=3, log=lambda *_: None)
+        hist = train.run(episodes=2, games=16, sims=24, eval_games=6, device="cuda:0", seed=3, log=lambda *_: None,
+                         device_replay=device_replay)
     finally:
         constants.BATCHES_PER_EPISODE, constants.NUM_EPOCHS, constants.BATCH_SIZE = saved
     assert len(hist) == 2
