@@ -21,6 +21,8 @@ STATE_DICT_ORDER = [
 
 
 def build(force=False):
+    if os.environ.get("AZ_ORACLE_LIB"):          # e.g. the sanitizer build (make -C oracle liboracle_asan.so)
+        return os.environ["AZ_ORACLE_LIB"]
     so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "az_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
