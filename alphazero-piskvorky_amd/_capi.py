@@ -27,7 +27,7 @@ AZ_MODEL_PLAIN, AZ_MODEL_RESNET = 0, 1
 EXPORTS = [
     "az_create", "az_destroy", "az_last_error", "az_load_weights", "az_load_weights_resnet", "az_net_eval", "az_search", "az_selfplay",
     "az_selfplay_begin", "az_selfplay_step", "az_selfplay_end", "az_selfplay_games", "az_selfplay_records", "az_record_bytes", "az_selfplay_pack", "az_examples_from_packed",
-    "az_examples_gather", "az_arena", "az_rng_selfplay_tape", "az_rng_uniforms", "az_set_profiling", "az_get_counters",
+    "az_examples_gather", "az_arena", "az_rng_selfplay_tape", "az_rng_uniforms", "az_set_profiling", "az_set_subtree_reuse", "az_get_counters",
 ]
 
 
@@ -306,6 +306,10 @@ class Engine:
         return dict(wins=res.wins, losses=res.losses, draws=res.draws, total=res.total, win_rate=res.win_rate,
                     results=results, actions=actions, nply=nply)
 
+    def set_subtree_reuse(self, on):
+        """Opt-in: keep the chosen child's subtree for the next ply (mcts.py:17-22 TODO); see include/az_engine.h."""
+        self._check(lib().az_set_subtree_reuse(self.h, 1 if on else 0), "az_set_subtree_reuse")
+
     def set_profiling(self, on):
         lib().az_set_profiling(self.h, 1 if on else 0)
 
@@ -335,6 +339,10 @@ class MultiEngine:
     def load_weights(self, sd, slot=0):
         for p in self.parts:
             p.load_weights(sd, slot)
+
+    def set_subtree_reuse(self, on):
+        for p in self.parts:
+            p.set_subtree_reuse(on)
 
     def selfplay_begin(self, num_games, seed0=0, max_plies=0, temperature_table=None):
         per = (num_games + self.K - 1) // self.K

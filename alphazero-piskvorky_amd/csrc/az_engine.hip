@@ -45,6 +45,55 @@ struct PackedNet {
     ResWeights rw{};
 };
 
+// Process-wide stream pool.  The runtime maps the streams of one priority level onto a small pool of hardware queues
+// when they are created; engines that come and go (a new MultiEngine per configuration, the evaluator's engine, a tape
+// producer per episode) would otherwise keep creating streams, and a later set of four engines can end up two to a
+// hardware queue (measured: a 15x15 episode 11.6 -> 14.7 s after two create/destroy cycles).  Streams are therefore
+// never destroyed: a released stream is synchronised and handed to the next engine on that device.
+// Play streams are non-blocking and HIGH priority -- not for urgency: high-priority streams draw their hardware queues
+// from a pool of their own, so next to a framework that has already created streams (PyTorch's context) the four
+// engines of a GPU still get a queue each (measured: episode 15.3 -> 11.6 s through SelfPlayManager).
+struct StreamPool {
+    std::mutex mu;
+    std::vector<hipStream_t> idle[16][2];      // [device][0 = normal priority copy streams, 1 = high priority play streams]
+    bool primed[16] = {};
+    static hipError_t create(bool high, hipStream_t *out)
+    {
+        int least = 0, greatest = 0;
+        const char *sp = getenv("AZ_STREAM_PRIORITY");     // AZ_STREAM_PRIORITY=0: default priority for the play streams too
+        if (high && !(sp && sp[0] == '0') && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least)
+            return hipStreamCreateWithPriority(out, hipStreamNonBlocking, greatest);
+        return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    }
+    hipError_t acquire(int device, bool high, hipStream_t *out)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        std::vector<hipStream_t> &v = idle[device & 15][high ? 1 : 0];
+        if (high && !primed[device & 15]) {
+            // the first engine on a device creates the play streams of a whole MultiEngine back to back: the queues of
+            // a set created in one go overlap well, a set pieced together around other queue creations may not
+            // (measured: an engine that played before the four were created cost them 12 %)
+            primed[device & 15] = true;
+            for (int i = 0; i < 4; i++) {
+                hipStream_t s = nullptr;
+                hipError_t rc = create(true, &s);
+                if (rc != hipSuccess) return rc;
+                v.insert(v.begin(), s);
+            }
+        }
+        if (!v.empty()) { *out = v.back(); v.pop_back(); return hipSuccess; }
+        return create(high, out);
+    }
+    void release(int device, bool high, hipStream_t s)
+    {
+        if (!s) return;
+        (void)hipStreamSynchronize(s);
+        std::lock_guard<std::mutex> lk(mu);
+        idle[device & 15][high ? 1 : 0].push_back(s);
+    }
+};
+static StreamPool g_streams;
+
 // Streams the self-play RNG tapes to the device a few plies ahead of the games instead of generating all n^2 plies of
 // every game before the first move (26 M legacy-gamma draws for 1024 games at 15x15, ~4 s of host time, most of it for
 // plies the games never reach).  The draws are trajectory-independent, so "wave" w = plies [wP, wP+P) of
@@ -87,7 +136,7 @@ struct TapeProducer {
         }
         if ((rc = hipHostMalloc((void **)&h_done, (size_t)G * sizeof(int), hipHostMallocDefault))) return rc;
         memset(h_done, 0, (size_t)G * sizeof(int));
-        if ((rc = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking))) return rc;
+        if ((rc = g_streams.acquire(device, false, &copy_stream))) return rc;
         wave_event.assign((size_t)waves, nullptr);
         for (int w = 0; w < waves; w++)
             if ((rc = hipEventCreateWithFlags(&wave_event[w], hipEventDisableTiming))) return rc;
@@ -165,7 +214,7 @@ struct TapeProducer {
         }
         cv.notify_all();
         if (th.joinable()) th.join();
-        if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
+        if (copy_stream) { g_streams.release(device, false, copy_stream); copy_stream = nullptr; }
         for (hipEvent_t ev : wave_event) if (ev) (void)hipEventDestroy(ev);
         wave_event.clear();
         for (int b = 0; b < 2; b++) {
@@ -189,7 +238,7 @@ struct az_engine {
     DevState d{};
     // per-engine buffers
     DevBuf board, s_game, s_ply, s_player, s_last, s_status, s_net, edges, rows_used, path, depth, leaf_kind, leaf,
-        leaf_last, logits, vhid, pol_feat, T_table, log_table, sqrt_table, noise_off, cnt, next_game, active;
+        leaf_last, logits, vhid, pol_feat, T_table, log_table, sqrt_table, noise_off, cnt, next_game, active, carried;
     // per-episode buffers
     DevBuf dbg, scratch;
     int split_max = 32;            // use the split (low-latency) trunk when at most this many slots are active (measured crossover)
@@ -207,6 +256,7 @@ struct az_engine {
         bool add_noise = true, arena = false, preset = false, profile = true;
         az_counters c{};
         double trunk_ms = 0.0, nn_ms = 0.0, step_ms = 0.0;
+        int64_t reused_roots = 0;
     } run;
     // profiling events
     std::vector<hipEvent_t> ev;
@@ -524,14 +574,7 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
     // hardware queues, so next to a framework that has already created streams (PyTorch's context) two engines can
     // land on one queue and stop overlapping (measured: episode 11.6 -> 15.3 s).  High-priority streams draw from
     // their own pool.  AZ_STREAM_PRIORITY=0 keeps the default priority.
-    if (hr == hipSuccess) {
-        int least = 0, greatest = 0;
-        const char *sp = getenv("AZ_STREAM_PRIORITY");
-        if (!(sp && sp[0] == '0') && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least)
-            hr = hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, greatest);
-        else
-            hr = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-    }
+    if (hr == hipSuccess) hr = g_streams.acquire(cfg->device, true, &e->stream);
     if (hr != hipSuccess) {
         int rc = fail(nullptr, AZ_ERR_HIP, "device init failed: %s", hipGetErrorString(hr));
         delete e;
@@ -549,7 +592,8 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
     ALLOC(leaf_kind, B * 4); ALLOC(leaf, B * 8 * sizeof(u64)); ALLOC(leaf_last, B * 4);
     ALLOC(logits, B * (size_t)e->RW * 4); ALLOC(vhid, B * 64 * 4);
     ALLOC(pol_feat, B * (size_t)((((cfg->model == AZ_MODEL_RESNET ? 3 : 6) * e->nn + 3) / 4) * 4) * 4);   // feature rows [B][FROW], zero tail stays zero
-    ALLOC(cnt, B * 4 * sizeof(unsigned long long)); ALLOC(next_game, 16); ALLOC(active, 16);
+    ALLOC(cnt, B * CNT_STRIDE * sizeof(unsigned long long)); ALLOC(next_game, 16); ALLOC(active, 16);
+    ALLOC(carried, B * 4);
     ALLOC(T_table, (size_t)(e->nn + 4) * sizeof(double));
 #ifdef AZ_STAMPS
     ALLOC(dbg, (B * 16 + 4096 * 32) * sizeof(unsigned long long));
@@ -574,6 +618,7 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
     d.T_table = (const double *)e->T_table.p; d.log_table = (const float *)e->log_table.p;
     d.sqrt_table = (const double *)e->sqrt_table.p; d.noise_off = (const int *)e->noise_off.p;
     d.cnt = (unsigned long long *)e->cnt.p; d.next_game = (int *)e->next_game.p; d.active = (int *)e->active.p;
+    d.carried = (int *)e->carried.p; d.reuse = 0;
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
@@ -621,7 +666,7 @@ extern "C" void az_destroy(az_engine *e)
     DevBuf *all[] = {&e->board, &e->s_game, &e->s_ply, &e->s_player, &e->s_last, &e->s_status, &e->s_net, &e->edges,
                      &e->rows_used, &e->path, &e->depth, &e->leaf_kind, &e->leaf, &e->leaf_last, &e->logits, &e->vhid,
                      &e->pol_feat, &e->T_table, &e->log_table, &e->sqrt_table, &e->noise_off, &e->cnt,
-                     &e->next_game, &e->active, &e->scratch, &e->noise, &e->u, &e->rec_planes, &e->rec_last, &e->rec_action,
+                     &e->next_game, &e->active, &e->carried, &e->scratch, &e->noise, &e->u, &e->rec_planes, &e->rec_last, &e->rec_action,
                      &e->rec_mover, &e->rec_pi, &e->rec_visits, &e->g_nply, &e->g_result, &e->src_index};
     for (DevBuf *b : all) dev_free(*b);
     for (int s = 0; s < 2; s++) {
@@ -633,7 +678,7 @@ extern "C" void az_destroy(az_engine *e)
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
     for (int i = 0; i < 4; i++)
         if (e->graph[i >> 1][i & 1].exec) (void)hipGraphExecDestroy(e->graph[i >> 1][i & 1].exec);
-    if (e->stream) (void)hipStreamDestroy(e->stream);
+    g_streams.release(e->cfg.device, true, e->stream);
     delete e;
 }
 
@@ -752,6 +797,7 @@ static int episode_begin(az_engine *e, const EpisodeSpec &sp)
     d.max_plies = sp.max_plies; d.add_noise = sp.add_noise ? 1 : 0; d.arena = sp.arena ? 1 : 0;
     d.total_games = sp.num_games;
     HIPCHECK(e, hipMemsetAsync(e->cnt.p, 0, e->cnt.bytes, e->stream));
+    HIPCHECK(e, hipMemsetAsync(e->carried.p, 0xFF, e->carried.bytes, e->stream));      // -1: every slot starts from a fresh root
     az_engine::Run &r = e->run;
     r = az_engine::Run();
     e->plies_played = 0;
@@ -895,19 +941,22 @@ static int episode_plies(az_engine *e, int max_steps)
 static int read_counters(az_engine *e, az_counters &c)
 {
     DevState &d = e->d;
-    std::vector<unsigned long long> hc((size_t)d.B * 4);
+    std::vector<unsigned long long> hc((size_t)d.B * CNT_STRIDE);
     HIPCHECK(e, az_memcpy(e->stream, hc.data(), e->cnt.p, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     c.expansions = c.simulations = c.terminal_hits = c.depth_sum = 0;
+    int64_t reused = 0;
     for (int b = 0; b < d.B; b++) {
-        c.expansions += (int64_t)hc[(size_t)b * 4 + 0];
-        c.simulations += (int64_t)hc[(size_t)b * 4 + 1];
-        c.terminal_hits += (int64_t)hc[(size_t)b * 4 + 2];
-        c.depth_sum += (int64_t)hc[(size_t)b * 4 + 3];
+        c.expansions += (int64_t)hc[(size_t)b * CNT_STRIDE + 0];
+        c.simulations += (int64_t)hc[(size_t)b * CNT_STRIDE + 1];
+        c.terminal_hits += (int64_t)hc[(size_t)b * CNT_STRIDE + 2];
+        c.depth_sum += (int64_t)hc[(size_t)b * CNT_STRIDE + 3];
+        reused += (int64_t)hc[(size_t)b * CNT_STRIDE + 4];
     }
+    e->run.reused_roots = reused;
     c.trunk_seconds = e->run.trunk_ms * 1e-3;
     c.nn_seconds = e->run.nn_ms * 1e-3;
     c.step_seconds = e->run.step_ms * 1e-3;
-    c.root_evals = c.plies;
+    c.root_evals = c.plies - reused;      // a retained root (subtree reuse) is not evaluated again
     c.records = c.plies;
     c.trunk_boards = c.expansions + c.root_evals;
     c.games = e->run.num_games;
@@ -937,7 +986,8 @@ static int episode_end(az_engine *e, az_counters *out)
     }
     int64_t plies = 0;
     for (int g = 0; g < r.num_games; g++) plies += e->h_nply[g];
-    r.c.plies = r.c.records = r.c.root_evals = plies;
+    r.c.plies = r.c.records = plies;
+    r.c.root_evals = plies - r.reused_roots;
     r.c.trunk_boards = r.c.expansions + r.c.root_evals;
     e->last = r.c;
     e->episode_games = r.num_games;
@@ -1304,6 +1354,16 @@ extern "C" int az_examples_gather(az_engine *e, const void *packed_dev, const in
                        states_dev, pis_dev, z_dev);
     HIPCHECK(e, hipStreamSynchronize(e->stream));
     HIPCHECK(e, hipGetLastError());
+    return AZ_OK;
+}
+
+extern "C" int az_set_subtree_reuse(az_engine *e, int on)
+{
+    if (!e) return AZ_ERR_INVALID;
+    if (e->run.open) return fail(e, AZ_ERR_STATE, "az_set_subtree_reuse: an episode is open");
+    if (on && e->R > REUSE_MAX_ROWS)
+        return fail(e, AZ_ERR_INVALID, "subtree reuse supports at most %d simulations per move", REUSE_MAX_ROWS - 1);
+    e->d.reuse = on ? 1 : 0;
     return AZ_OK;
 }
 

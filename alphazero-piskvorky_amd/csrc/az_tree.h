@@ -9,7 +9,10 @@
 #pragma once
 #include "az_device.h"
 
-enum { LEAF_NONE = 0, LEAF_EXPAND = 1, LEAF_TERM_LOSS = 2, LEAF_TERM_DRAW = 3, LEAF_ROOT = 4 };
+enum { LEAF_NONE = 0, LEAF_EXPAND = 1, LEAF_TERM_LOSS = 2, LEAF_TERM_DRAW = 3, LEAF_ROOT = 4,
+       LEAF_REUSE = 5 };      // root retained from the previous ply's search (subtree reuse): no evaluation, noise mix only
+constexpr int REUSE_MAX_ROWS = 1024;   // rows per slot (S + 2) the in-place compaction of k_move can renumber
+constexpr int CNT_STRIDE = 8;  // per-slot counters: expansions, simulations, terminal hits, depth sum, reused roots
 enum { SLOT_IDLE = 0, SLOT_ACTIVE = 1, SLOT_FINISHED = 2 };
 
 struct __attribute__((aligned(16))) Edge {
@@ -56,7 +59,10 @@ struct DevState {
     unsigned short *rec_visits; // [G*nn][nn]
     int *g_nply, *g_result;
     // --- bookkeeping ---
-    unsigned long long *cnt;   // [B][4] expansions, simulations, terminal hits, depth sum
+    unsigned long long *cnt;   // [B][CNT_STRIDE] expansions, simulations, terminal hits, depth sum, reused roots
+    // --- opt-in subtree reuse between plies (the reference's TODO, mcts.py:17-22,106) ---
+    int reuse;             // 0: every ply searches from a fresh root like the reference
+    int *carried;          // [B] visits the retained root already holds (sum of its children's N), -1 = fresh root
     int *next_game;        // device counter
     int *active;           // number of active slots after refill
 };
@@ -145,7 +151,7 @@ __global__ void k_begin(DevState d)
         lf[4 + i] = pl == 1 ? bd[4 + i] : bd[i];
     }
     d.leaf_last[b] = d.s_last[b];
-    d.leaf_kind[b] = LEAF_ROOT;
+    d.leaf_kind[b] = (d.reuse && d.carried[b] >= 0) ? LEAF_REUSE : LEAF_ROOT;
     d.depth[b] = 0;
     d.s_net[b] = d.arena ? (pl == 1 ? 0 : 1) : 0;   // evaluator.py:73-79: each side searches with its own net
 }
@@ -180,6 +186,7 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
     const int leaf_last = d.leaf_last[bb];
     const int game = d.s_game[bb];
     const int ply = d.s_ply[bb];
+    const int carried = d.reuse ? d.carried[bb] : -1;
     const Plane lme = pl_load(d.leaf + (size_t)bb * 8), lopp = pl_load(d.leaf + (size_t)bb * 8 + 4);
     const Plane bX = pl_load(d.board + (size_t)bb * 8), bO = pl_load(d.board + (size_t)bb * 8 + 4);
     unsigned *path = d.path + (size_t)bb * G::PATH;
@@ -200,7 +207,28 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
     Edge *rows = d.edges + (size_t)b * d.R * G::RW;
 
     // ---------------- stage 1: evaluation -> expand -> backup ----------------
-    if (kind != LEAF_NONE) {
+    if (kind == LEAF_REUSE) {
+        // retained root: its row (compacted to row 0 by k_move) already holds the un-noised priors and the visit
+        // statistics of the previous search; only the fresh Dirichlet sample is mixed in (same arithmetic as a new root)
+        if (d.add_noise) {
+            Plane occ;
+#pragma unroll
+            for (int q = 0; q < 4; q++) occ.w[q] = bX.w[q] | bO.w[q];
+            const double *nz = d.noise + (size_t)game * d.noise_stride + d.noise_off[ply];
+#pragma unroll
+            for (int i = 0; i < G::CPL; i++) {
+                int j = lane + 64 * i;
+                if (j < G::nn && !pl_get(occ, j)) {
+                    int rank = j - pl_rank(occ, j);
+                    Edge *e = rows + j;
+                    float scaled = d.one_minus_w * e->P;
+                    e->P = (float)((double)scaled + d.w_noise * nz[rank]);
+                }
+            }
+        }
+        if (lane == 0) d.cnt[(size_t)b * CNT_STRIDE + 4] += 1ull;
+        wave_mem_sync();
+    } else if (kind != LEAF_NONE) {
         float v = 0.0f;
         if (kind == LEAF_ROOT || kind == LEAF_EXPAND) {
             float P[G::CPL];
@@ -295,7 +323,7 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
                 e->W = e->W + val;
             }
             if (lane == 0) {
-                unsigned long long *c = d.cnt + (size_t)b * 4;
+                unsigned long long *c = d.cnt + (size_t)b * CNT_STRIDE;
                 c[0] += kind == LEAF_EXPAND ? 1ull : 0ull;
                 c[1] += 1ull;
                 c[2] += kind == LEAF_EXPAND ? 0ull : 1ull;
@@ -306,7 +334,7 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
     }
 
     // ---------------- stage 2: selection (mcts.py:124-129) ----------------
-    if (!do_select) {
+    if (!do_select || rootN < carried) {          // a retained root tops its visits up to S: idle until simulation `carried`
         if (lane == 0) d.leaf_kind[b] = LEAF_NONE;
         return;
     }
@@ -385,6 +413,7 @@ __global__ __launch_bounds__(256) void k_move(DevState d)
 {
     typedef TreeGeo<N> G;
     __shared__ double ebuf_all[4][G::RW];
+    __shared__ unsigned short idx_all[4][REUSE_MAX_ROWS];   // subtree reuse: new row index of every kept row
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wv;
@@ -520,6 +549,61 @@ __global__ __launch_bounds__(256) void k_move(DevState d)
         }
         d.leaf_kind[b] = LEAF_NONE;
     }
+    if (!d.reuse) return;
+    // ---- subtree reuse: the chosen child's subtree becomes the next ply's tree ----
+    // Rows are created in visiting order, so a child row always has a larger index than its parent: one ascending
+    // pass marks the rows reachable from the child, a second one moves them down in place (destination <= source)
+    // and renumbers the child links (R <= REUSE_MAX_ROWS, checked by az_set_subtree_reuse).
+    {
+        const bool cont = !(win || full) && !(d.max_plies > 0 && ply + 1 >= d.max_plies) && !d.arena;
+        Edge *rows = d.edges + (size_t)b * d.R * G::RW;
+        const int c = cont ? (int)rows[a].child : 0;
+        if (c == 0) {
+            if (lane == 0) d.carried[b] = -1;
+            return;
+        }
+        unsigned short *idx = idx_all[wv];
+        const unsigned short NOT = 0xFFFFu, KEEP = 0xFFFEu;
+        const int used = d.rows_used[b];
+        wave_mem_sync();
+        for (int r = lane; r < used; r += 64) idx[r] = r == c ? KEEP : NOT;
+        wave_mem_sync();
+        for (int r = c; r < used; r++) {
+            if (idx[r] != KEEP) continue;                     // uniform: every lane reads the same LDS word
+#pragma unroll
+            for (int i = 0; i < G::CPL; i++) {
+                const unsigned short ch = rows[(size_t)r * G::RW + lane + 64 * i].child;
+                if (ch) idx[ch] = KEEP;
+            }
+            wave_mem_sync();
+        }
+        int kept = 0;
+        if (lane == 0) {
+            for (int r = c; r < used; r++)
+                if (idx[r] == KEEP) idx[r] = (unsigned short)kept++;
+        }
+        wave_mem_sync();
+        kept = __shfl(kept, 0, 64);
+        int csum = 0;
+        for (int r = c; r < used; r++) {
+            const unsigned short dst = idx[r];
+            if (dst == NOT) continue;
+            Edge e[G::CPL];
+#pragma unroll
+            for (int i = 0; i < G::CPL; i++) {
+                e[i] = rows[(size_t)r * G::RW + lane + 64 * i];
+                if (e[i].child) e[i].child = idx[e[i].child];
+                if (dst == 0) csum += (int)e[i].N;
+            }
+#pragma unroll
+            for (int i = 0; i < G::CPL; i++) rows[(size_t)dst * G::RW + lane + 64 * i] = e[i];
+        }
+        csum = wave_sum_i(csum);
+        if (lane == 0) {
+            d.rows_used[b] = kept;
+            d.carried[b] = csum;
+        }
+    }
 }
 
 #ifdef AZ_ENGINE_TU
@@ -558,6 +642,7 @@ __global__ __launch_bounds__(1024) void k_refill(DevState d)
                 d.s_last[b] = -1;
                 d.s_status[b] = SLOT_ACTIVE;
                 d.leaf_kind[b] = LEAF_NONE;
+                d.carried[b] = -1;
                 newact = 1;
             } else {
                 d.s_status[b] = SLOT_IDLE;
@@ -583,5 +668,6 @@ __global__ void k_set_position(DevState d, int slot, int game, int player, int l
     d.s_last[slot] = last;
     d.s_status[slot] = SLOT_ACTIVE;
     d.leaf_kind[slot] = LEAF_NONE;
+    d.carried[slot] = -1;
 }
 #endif  // AZ_ENGINE_TU

@@ -21,7 +21,7 @@ class SelfPlayManager:
     def __init__(self, controller, device, mcts_params: dict = None,
                  temperature_schedule: Callable[[int], float] = default_temperature_schedule,
                  concurrent_games: int = None, augmentation: int = AZ_AUG_REFERENCE4, seed: int = None,
-                 engines_per_gpu: int = None):
+                 engines_per_gpu: int = None, subtree_reuse: bool = False):
         self.controller = controller
         self.device = device
         self.mcts_params = mcts_params or {"num_simulations": 100}
@@ -30,6 +30,7 @@ class SelfPlayManager:
         self.augmentation = augmentation      # 4 = the reference's rotations (self_play.py:94-108), 8 = full dihedral group, 1 = none
         self.seed = seed
         self.engines_per_gpu = engines_per_gpu or _c.ENGINES_PER_GPU
+        self.subtree_reuse = subtree_reuse    # opt-in search upgrade (mcts.py:17-22 TODO); off = the reference's fresh root every move
         self.last_counters = None
         self._engine = None
 
@@ -79,6 +80,7 @@ class SelfPlayManager:
         dev = torch.device("cuda", device_index(self.device))
         eng = self._eng(n, k, max(1, min(self.concurrent_games, max(mine, 1))))
         eng.load_weights(self.controller.net.state_dict(), 0)
+        eng.set_subtree_reuse(self.subtree_reuse)
         T = np.array([float(self.temperature_schedule(m)) for m in range(n * n + 1)], dtype=np.float64)
         if mine > 0:
             self.last_counters = eng.selfplay(mine, seed0=seed0 + lo, temperature_table=T)

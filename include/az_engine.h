@@ -192,6 +192,16 @@ int az_arena(az_engine *e, const az_arena_args *args, az_arena_result *out, int3
 int az_rng_selfplay_tape(uint64_t seed, int board_size, double alpha, int max_plies, double *noise, double *u);
 int az_rng_uniforms(uint64_t seed, int count, double *u);
 
+/* Opt-in search upgrade the reference lists as a TODO (mcts.py:17-22 "subtree reuse", mcts.py:106 builds a new root
+ * every run): after a self-play move the chosen child's subtree becomes the next ply's tree.  The retained root keeps
+ * its priors and visit statistics, receives the ply's fresh Dirichlet sample with the arithmetic of a new root
+ * (mcts.py:113-116), is NOT evaluated again, and the search runs only the simulations that top its children's visits
+ * up to num_simulations, so pi is still a distribution over num_simulations visits.  Off by default: with it the visit
+ * counts differ from the reference's (parity is then against the oracle's restatement of this rule, "parity
+ * unpinned" by the reference).  Self-play only; arena games and az_search always start from a fresh root.  Needs
+ * num_simulations <= 1023.  Not allowed while an episode is open. */
+int az_set_subtree_reuse(az_engine *e, int on);
+
 /* HIP-event timing of every trunk / FC / tree-step launch (az_counters.trunk_seconds, nn_seconds, step_seconds);
  * off by default: four events per evaluation batch cost a few microseconds of stream time, which matters on small boards. */
 int az_set_profiling(az_engine *e, int on);

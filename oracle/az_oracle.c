@@ -449,6 +449,8 @@ typedef struct {
     double c_puct, alpha, w;
     int eval_kind;              /* 0 = net, 1 = synthetic */
     const float *log_table;     /* log_table[N] = np.log(float32(N)+1e-8) as float32, N = 0..S; NULL -> logf */
+    int reuse;                  /* opt-in subtree reuse between the plies of a self-play game (include/az_engine.h,
+                                   az_set_subtree_reuse); 0 = the reference's behaviour (new root every run, mcts.py:106) */
 } orc_cfg;
 
 typedef struct {
@@ -462,6 +464,8 @@ typedef struct {
 typedef struct {
     orc_node *nodes; int used, cap;
     long expansions, sims, terminal_hits, depth_sum;
+    int retained;               /* subtree reuse: nodes[0] is an already expanded root kept from the previous ply */
+    long reused_roots;
 } orc_tree;
 
 static void evaluate(const orc_cfg *cfg, const orc_net *net, const orc_state *s, float *P, float *v)
@@ -557,8 +561,29 @@ static int mcts_run(const orc_cfg *cfg, const orc_net *net, const orc_state *roo
 {
     int n = cfg->n, nn = n * n;
     float P[ORC_MAXNN], v;
-    t->used = 1;
+    int first_sim = 0;
     orc_node *root = &t->nodes[0];
+    if (t->retained) {
+        /* subtree reuse (not in the reference): the root kept from the previous ply is not evaluated again; its
+         * children keep priors and statistics, the fresh Dirichlet sample is mixed in with a new root's arithmetic,
+         * and only the simulations that top the children's visits up to S are run.  root->N = visits of its children,
+         * the quantity a fresh root's N holds after the same number of simulations. */
+        int carried = 0;
+        float om = (float)(1.0 - cfg->w);
+        for (int i = 0; i < root->cnt; i++) {
+            orc_node *c = &t->nodes[root->first + i];
+            carried += c->N;
+            if (noise) {
+                float scaled = om * (float)c->prior;
+                c->prior = (double)(float)((double)scaled + cfg->w * noise[i]);
+            }
+        }
+        root->N = carried;
+        first_sim = carried;
+        t->retained = 0;
+        t->reused_roots++;
+    } else {
+    t->used = 1;
     root->parent = -1; root->action = -1; root->prior = 1.0; root->N = 0; root->W = 0.0; root->first = -1; root->cnt = 0;
 
     evaluate(cfg, net, root_state, P, &v);            /* mcts.py:109 (root value discarded) */
@@ -573,8 +598,9 @@ static int mcts_run(const orc_cfg *cfg, const orc_net *net, const orc_state *roo
         }
     }
     expand(t, 0, root_state, P);                      /* mcts.py:120 */
+    }
     int maxd = 0;
-    for (int sim = 0; sim < cfg->S; sim++) {          /* mcts.py:123 */
+    for (int sim = first_sim; sim < cfg->S; sim++) {  /* mcts.py:123 */
         int node = 0, depth = 0;
         orc_state s = *root_state;                    /* clone */
         s.winner = root_state->winner;
@@ -623,6 +649,35 @@ static orc_tree *tree_new(const orc_cfg *cfg)
     return t;
 }
 static void tree_free(orc_tree *t) { free(t->nodes); free(t); }
+
+/* subtree reuse: the subtree below root child `action` becomes the whole tree (breadth-first copy, children blocks stay
+ * contiguous and in row-major order).  Returns 0 and leaves the tree alone when that child was never expanded. */
+static int tree_reroot(orc_tree *t, int action)
+{
+    const orc_node *root = &t->nodes[0];
+    int c = -1;
+    for (int i = 0; i < root->cnt; i++)
+        if (t->nodes[root->first + i].action == action) c = root->first + i;
+    if (c < 0 || t->nodes[c].cnt == 0) return 0;
+    orc_node *nn_ = (orc_node *)malloc(sizeof(orc_node) * (size_t)t->cap);
+    int *old_of = (int *)malloc(sizeof(int) * (size_t)t->cap);
+    int used = 1;
+    nn_[0] = t->nodes[c]; nn_[0].parent = -1; old_of[0] = c;
+    for (int i = 0; i < used; i++) {
+        const orc_node *o = &t->nodes[old_of[i]];
+        if (o->cnt == 0) continue;
+        nn_[i].first = used;
+        for (int j = 0; j < o->cnt; j++) {
+            nn_[used] = t->nodes[o->first + j];
+            nn_[used].parent = i;
+            old_of[used] = o->first + j;
+            used++;
+        }
+    }
+    free(t->nodes); free(old_of);
+    t->nodes = nn_; t->used = used; t->retained = 1;
+    return 1;
+}
 
 /* single search from an arbitrary position; also returns the root children's statistics */
 int orc_search(const orc_cfg *cfg, const orc_net *net, const uint8_t *board, int player, int last, double T,
@@ -678,12 +733,13 @@ int orc_selfplay_game(const orc_cfg *cfg, const orc_net *net, const double *nois
         noff += (size_t)(nn - m);
         st_apply(&s, a);                                     /* self_play.py:64 */
         m++;
+        if (cfg->reuse && !st_terminal(&s) && m < maxply) tree_reroot(t, a);
     }
     int res = st_terminal(&s) ? s.winner : RES_NONE;
     for (int i = 0; i < m; i++)                              /* self_play.py:71 */
         z[i] = (int8_t)(res == RES_NONE ? 99 : (res == RES_DRAW ? 0 : (movers[i] == res ? 1 : -1)));
     if (result_out) *result_out = res;
-    if (counters) { counters[0] = t->expansions; counters[1] = t->sims; counters[2] = t->terminal_hits; counters[3] = t->depth_sum; counters[4] = m; }
+    if (counters) { counters[0] = t->expansions; counters[1] = t->sims; counters[2] = t->terminal_hits; counters[3] = t->depth_sum; counters[4] = m - t->reused_roots; }
     tree_free(t);
     return m;
 }

@@ -33,7 +33,7 @@ def build(force=False):
 class _Cfg(C.Structure):
     _fields_ = [("n", C.c_int), ("k", C.c_int), ("S", C.c_int),
                 ("c_puct", C.c_double), ("alpha", C.c_double), ("w", C.c_double),
-                ("eval_kind", C.c_int), ("log_table", C.POINTER(C.c_float))]
+                ("eval_kind", C.c_int), ("log_table", C.POINTER(C.c_float)), ("reuse", C.c_int)]
 
 
 def lib():
@@ -116,11 +116,11 @@ class Net:
 
 
 class Oracle:
-    def __init__(self, n, k, S, c_puct=2.0, alpha=0.3, w=0.25, synthetic=False, log_table=None):
+    def __init__(self, n, k, S, c_puct=2.0, alpha=0.3, w=0.25, synthetic=False, log_table=None, reuse=False):
         self.n, self.k, self.S = n, k, S
         self.log_table = numpy_log_table(max(S, 1)) if log_table is None else np.ascontiguousarray(log_table, np.float32)
         self.cfg = _Cfg(n, k, S, c_puct, alpha, w, 1 if synthetic else 0,
-                        self.log_table.ctypes.data_as(C.POINTER(C.c_float)))
+                        self.log_table.ctypes.data_as(C.POINTER(C.c_float)), 1 if reuse else 0)
 
     # ---- rules ----
     def replay(self, actions):
