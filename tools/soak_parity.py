@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Full-size parity soak (not part of the regular suite: minutes of host time): complete self-play games at the BASELINE
+configuration, engine vs the CPU oracle, every ply of every game bit for bit (boards, visit counts, pi, actions, z).
+usage: soak_parity.py [games] [model plain|resnet] [sims] [out.json]"""
+import json, os, sys, time
+from concurrent.futures import ThreadPoolExecutor
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import alphazero_piskvorky_amd as az
+from alphazero_piskvorky_amd.weights import synthetic_state_dict, synthetic_resnet_state_dict
+from alphazero_piskvorky_amd.net import fold_resnet_state_dict
+from oracle import oracle as orc
+
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+model = sys.argv[2] if len(sys.argv) > 2 else "plain"
+S = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+out = sys.argv[4] if len(sys.argv) > 4 else None
+n, k, seed0 = 15, 5, 1_000_000
+sd = synthetic_resnet_state_dict(n) if model == "resnet" else synthetic_state_dict(n)
+eng = az.MultiEngine(n, k, S, G, engines=4, log_table=orc.numpy_log_table(S), model=model)
+eng.load_weights(sd, 0)
+t0 = time.perf_counter()
+c = eng.selfplay(G, seed0=seed0)
+t_gpu = time.perf_counter() - t0
+rec = eng.records(); nply, res = eng.games()
+starts = np.concatenate([[0], np.cumsum(nply)])
+onet = orc.Net(n, resnet_tensors=fold_resnet_state_dict(sd)) if model == "resnet" else orc.Net(n, sd)
+o = orc.Oracle(n, k, S)
+
+def check(g):
+    noise, us = orc.selfplay_tape(seed0 + g, n)
+    r = o.selfplay_game(onet, noise, us)
+    sl = slice(int(starts[g]), int(starts[g + 1]))
+    bad = [key for key in ("actions", "boards", "movers", "visits", "pis", "z", "lasts") if not np.array_equal(rec[key][sl], r[key])]
+    return g, r["nply"], int(nply[g]), r["result"], int(res[g]), bad, r["counters"]["expansions"]
+
+t1 = time.perf_counter()
+with ThreadPoolExecutor(os.cpu_count() or 8) as pool:
+    rows = list(pool.map(check, range(G)))
+t_cpu = time.perf_counter() - t1
+fails = [r for r in rows if r[5] or r[1] != r[2] or r[3] != r[4]]
+summary = {"config": f"15x15/5, {S} sims, {model} net, {G} complete games, seeds {seed0}..", "plies": int(nply.sum()),
+           "expansions_engine": int(c["expansions"]), "expansions_oracle": int(sum(r[6] for r in rows)),
+           "games_bit_exact": G - len(fails), "games": G, "gpu_seconds": round(t_gpu, 2), "oracle_seconds": round(t_cpu, 1),
+           "oracle_threads": os.cpu_count(), "compared": "actions, boards, movers, visit counts, pi (f32 bit patterns), z, last moves, per ply"}
+print(json.dumps(summary))
+if fails:
+    print("MISMATCH", fails[:5])
+if out:
+    json.dump(summary, open(out, "w"), indent=1)
+sys.exit(1 if fails or summary["expansions_engine"] != summary["expansions_oracle"] else 0)
