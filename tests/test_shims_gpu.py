@@ -88,6 +88,22 @@ def test_generate_self_play_contract():
     assert len(d2) == len(d3) and all(np.array_equal(a[1], b[1]) and a[2] == b[2] for a, b in zip(d2, d3))
 
 
+def test_generate_self_play_with_subtree_reuse_keeps_the_example_contract():
+    """SelfPlayManager(subtree_reuse=True): same record contract, fewer simulations, slot-count independent."""
+    outs = []
+    for slots in (4, 9):
+        mgr = SelfPlayManager(_controller("ckpt_saved"), "cuda:0", mcts_params={"num_simulations": 40, "c_puct": 2.0},
+                              concurrent_games=slots, seed=78, subtree_reuse=True)
+        data = mgr.generate_self_play(num_games=9)
+        c = mgr.last_counters
+        assert len(data) == 4 * c["plies"] and c["simulations"] < 40 * c["plies"] and c["root_evals"] < c["plies"]
+        assert all(abs(float(pp.sum()) - 1.0) < 1e-5 for _, pp, _ in data[::5]) and set(zz for _, _, zz in data) <= {-1, 0, 1}
+        raw = mgr._engine.records()
+        assert (raw["visits"].sum(axis=1) == 40).all()                   # every root ends the ply with S visits below it
+        outs.append(data)
+    assert len(outs[0]) == len(outs[1]) and all(np.array_equal(a[1], b[1]) and a[2] == b[2] for a, b in zip(*outs))
+
+
 def test_model_evaluator_matches_reference_arena():
     z = load("arena_5x4.npz")
     constants.NUM_EVAL_SIMULATIONS = int(z["S"])
