@@ -642,8 +642,12 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
     const char *ts = getenv("AZ_TAPE_STREAM");
     e->stream_tapes = !(ts && ts[0] == '0');
     {
+        // default: the host threads of this rank (hardware threads / ranks on the node, torchrun's LOCAL_WORLD_SIZE)
+        // shared by the four engines of a GPU
         const unsigned hc = std::thread::hardware_concurrency();
-        int t = hc ? (int)hc / 8 : 2;
+        const char *lw = getenv("LOCAL_WORLD_SIZE");
+        const int ranks = lw && atoi(lw) > 0 ? atoi(lw) : 1;
+        int t = hc ? (int)hc / (4 * ranks) : 2;
         const char *tt = getenv("AZ_TAPE_THREADS");
         if (tt) t = atoi(tt);
         e->tape_threads = t < 1 ? 1 : (t > 16 ? 16 : t);
