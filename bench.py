@@ -51,12 +51,26 @@ def cpu_baseline(n, k, sims, sd, budget_games):
     def one(g):
         return o.selfplay_game(net, tapes[g][0], tapes[g][1], maxply=plies)["counters"]
 
+    # one game on one thread first ("1 thread and all-cores"), then one game per thread
+    t1 = time.perf_counter()
+    c1 = one(0)
+    dt1 = time.perf_counter() - t1
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
         cs = list(ex.map(one, range(games)))
     dt = time.perf_counter() - t0
     exp = sum(c["expansions"] + c["root_evals"] for c in cs)
+    cpu_model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": exp / dt, "unit": "node-expansions/s", "cores": cores, "kind": "port",
+            "single_thread_value": (c1["expansions"] + c1["root_evals"]) / dt1, "cpu_model": cpu_model,
+            "host_threads_total": os.cpu_count(),
             "sample": f"CPU oracle (C restatement of mcts.py/net.py), first {plies} plies of {games} games, "
                       f"{n}x{n}/{k}, {sims} sims, one game per thread, {dt:.1f}s",
             "seconds": dt}
