@@ -71,4 +71,4 @@ class DeviceReplayBuffer:
             self.engine.examples_gather(self.ring.data_ptr(), idx.data_ptr(), sym.data_ptr(), total,
                                         1 if aug == AZ_AUG_REFERENCE4 else 0, states.data_ptr(), pis.data_ptr(), zs.data_ptr())
         states, pis, zs = states.cpu(), pis.cpu().numpy(), zs.cpu().numpy().astype(np.int64)
-        return [(states[i], pis[i], int(zs[i])) for i in range(total)]
+        return list(zip(states.unbind(0), list(pis), zs.tolist()))

@@ -61,7 +61,7 @@ class SelfPlayManager:
             eng.examples_from_packed(packed.data_ptr(), total, aug, states.data_ptr(), pis.data_ptr(), zs.data_ptr())
         states, pis, zs = states.cpu(), pis.cpu().numpy(), zs.cpu().numpy().astype(np.int64)
         print(f"[SelfPlayManager] Collected {len(zs)} examples from {num_games} games.")
-        return [(states[i], pis[i], int(zs[i])) for i in range(len(zs))]
+        return list(zip(states.unbind(0), list(pis), zs.tolist()))     # (tensor view, ndarray view, int) per example
 
     def generate_packed(self, num_games: int):
         """The same episode, but the result stays on the device as packed records (one per position, all ranks'
