@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Full-size parity soak (not part of the regular suite: minutes of host time): complete self-play games at the BASELINE
 configuration, engine vs the CPU oracle, every ply of every game bit for bit (boards, visit counts, pi, actions, z).
-usage: soak_parity.py [games] [model plain|resnet] [sims] [out.json]"""
+usage: soak_parity.py [games] [model plain|resnet] [sims] [out.json|-] [board] [reuse] [ckpt]"""
 import json, os, sys, time
 from concurrent.futures import ThreadPoolExecutor
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,18 +14,26 @@ from oracle import oracle as orc
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 model = sys.argv[2] if len(sys.argv) > 2 else "plain"
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 400
-out = sys.argv[4] if len(sys.argv) > 4 else None
-n, k, seed0 = 15, 5, 1_000_000
-sd = synthetic_resnet_state_dict(n) if model == "resnet" else synthetic_state_dict(n)
-eng = az.MultiEngine(n, k, S, G, engines=4, log_table=orc.numpy_log_table(S), model=model)
+out = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] != "-" else None
+n = int(sys.argv[5]) if len(sys.argv) > 5 else 15          # optional: board size, "reuse" for subtree reuse, "ckpt" = trained 5x5 weights
+reuse = "reuse" in sys.argv[6:]
+k, seed0 = (4 if n <= 5 else 5), 1_000_000
+if "ckpt" in sys.argv[6:]:
+    from tests.util import weights_from_fixture
+    sd = weights_from_fixture(5, "ckpt_saved")
+else:
+    sd = synthetic_resnet_state_dict(n) if model == "resnet" else synthetic_state_dict(n)
+slots = max(4, G // 2)                                       # fewer slots than games: refills are part of the soak
+eng = az.MultiEngine(n, k, S, slots, engines=4, log_table=orc.numpy_log_table(S), model=model)
 eng.load_weights(sd, 0)
+eng.set_subtree_reuse(reuse)
 t0 = time.perf_counter()
 c = eng.selfplay(G, seed0=seed0)
 t_gpu = time.perf_counter() - t0
 rec = eng.records(); nply, res = eng.games()
 starts = np.concatenate([[0], np.cumsum(nply)])
 onet = orc.Net(n, resnet_tensors=fold_resnet_state_dict(sd)) if model == "resnet" else orc.Net(n, sd)
-o = orc.Oracle(n, k, S)
+o = orc.Oracle(n, k, S, reuse=reuse)
 
 def check(g):
     noise, us = orc.selfplay_tape(seed0 + g, n)
@@ -39,7 +47,8 @@ with ThreadPoolExecutor(os.cpu_count() or 8) as pool:
     rows = list(pool.map(check, range(G)))
 t_cpu = time.perf_counter() - t1
 fails = [r for r in rows if r[5] or r[1] != r[2] or r[3] != r[4]]
-summary = {"config": f"15x15/5, {S} sims, {model} net, {G} complete games, seeds {seed0}..", "plies": int(nply.sum()),
+summary = {"config": f"{n}x{n}/{k}, {S} sims, {model} net{' (trained 5x5 checkpoint)' if 'ckpt' in sys.argv[6:] else ''}, {G} complete games on {slots} slots"
+                     f"{', subtree reuse' if reuse else ''}, seeds {seed0}..", "plies": int(nply.sum()),
            "expansions_engine": int(c["expansions"]), "expansions_oracle": int(sum(r[6] for r in rows)),
            "games_bit_exact": G - len(fails), "games": G, "gpu_seconds": round(t_gpu, 2), "oracle_seconds": round(t_cpu, 1),
            "oracle_threads": os.cpu_count(), "compared": "actions, boards, movers, visit counts, pi (f32 bit patterns), z, last moves, per ply"}
