@@ -25,7 +25,8 @@ from .self_play import SelfPlayManager
 PROMOTION_THRESHOLD = 0.55          # promoter.py:19, strict ">" with draws counted one half
 
 
-def run(episodes, games, sims, eval_games, device="cuda:0", seed=0, model_dir=None, log=print, device_replay=False):
+def run(episodes, games, sims, eval_games, device="cuda:0", seed=0, model_dir=None, log=print, device_replay=False,
+        subtree_reuse=False):
     """device_replay=True keeps the examples on the GPU from the episode-end gather to the optimizer step (packed records
     in a device ring, batches unpacked + augmented by az_examples_gather) instead of materialising Python tuples."""
     torch.manual_seed(seed)
@@ -33,7 +34,7 @@ def run(episodes, games, sims, eval_games, device="cuda:0", seed=0, model_dir=No
     candidate = NeuralNetworkController(GomokuNet(board_size=n), device=device)
     model_dir = model_dir or tempfile.mkdtemp(prefix="az_models_")
     manager = SelfPlayManager(candidate, device, mcts_params={"num_simulations": sims, "c_puct": C.SELF_PLAY_EXPLORATION_CONSTANT},
-                              seed=seed)
+                              seed=seed, subtree_reuse=subtree_reuse)
     evaluator = ModelEvaluator(game_class=Gomoku, print_games=False, device=device, seed=seed)
     promoter = ModelPromoter(model_dir, evaluator, lambda: GomokuNet(board_size=n), device, threshold=PROMOTION_THRESHOLD)
     buffer = ReplayBuffer(capacity=C.BUFFER_CAPACITY)
@@ -81,6 +82,7 @@ def main():
     ap.add_argument("--eval-games", type=int, default=C.EVALUATION_GAMES)
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--model-dir", default=None)
+    ap.add_argument("--subtree-reuse", action="store_true", help="self-play keeps the chosen child's subtree between plies (opt-in search upgrade)")
     ap.add_argument("--device-replay", action="store_true", help="keep examples on the GPU (packed ring + on-device batch unpacking)")
     a = ap.parse_args()
     # one process per GPU under torch.distributed.run: games and arena games are sharded over the ranks (self_play.py,
@@ -94,7 +96,8 @@ def main():
         a.device = f"cuda:{local}"
         if td.get_rank() != 0 and a.model_dir is None:
             a.model_dir = tempfile.mkdtemp(prefix=f"az_models_rank{td.get_rank()}_")
-    run(a.episodes, a.games, a.sims, a.eval_games, a.device, model_dir=a.model_dir, device_replay=a.device_replay)
+    run(a.episodes, a.games, a.sims, a.eval_games, a.device, model_dir=a.model_dir, device_replay=a.device_replay,
+        subtree_reuse=a.subtree_reuse)
     if world > 1:
         td.barrier()
         td.destroy_process_group()

@@ -89,6 +89,7 @@ def main():
                     "one engine's tree/FC kernels overlap another's conv trunk); 0 = auto: 1 for 5x5 (launch-bound), 4 otherwise")
     ap.add_argument("--model", default="plain", choices=["plain", "resnet"], help="plain = GomokuNet (net.py); resnet = ResidualBlock variant (config 5)")
     ap.add_argument("--no-episode", action="store_true", help="skip playing the episode to its end")
+    ap.add_argument("--subtree-reuse", action="store_true", help="opt-in search upgrade (not the reference's algorithm): keep the chosen child's subtree between plies")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--pmc-run", action="store_true", help="counter-collection run: 8 sims per move so the pass stays short")
     a = ap.parse_args()
@@ -120,6 +121,8 @@ def main():
     sd = synthetic_resnet_state_dict(n) if a.model == "resnet" else synthetic_state_dict(n)
     eng = az.MultiEngine(n, k, S, B, engines=a.engines, device=local, model=a.model)
     eng.load_weights(sd, 0)
+    if a.subtree_reuse:
+        eng.set_subtree_reuse(True)
     # every rank plays its own shard of the episode's games: ids rank*B .. rank*B+B-1 (seed = seed0 + id)
     eng.selfplay_begin(B, seed0=1_000_000 + rank * B)
 
@@ -234,7 +237,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / max(a.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n}x{n} / {k}-in-a-row self-play, {B} concurrent games per GPU, {S} sims/move "
-                                   f"{'(BASELINE.json configs[3] per-GPU shard)' if (n, k, S, B, a.model) == (15, 5, 400, 1024, 'plain') else '(custom)'}, {'GomokuNet' if a.model == 'plain' else 'ResidualBlock net'} random-init weights, numpy-compatible RNG tapes",
+                                   f"{'(BASELINE.json configs[3] per-GPU shard)' if (n, k, S, B, a.model) == (15, 5, 400, 1024, 'plain') else '(custom)'}, {'GomokuNet' if a.model == 'plain' else 'ResidualBlock net'} random-init weights, numpy-compatible RNG tapes{', SUBTREE REUSE ON (not the reference algorithm)' if a.subtree_reuse else ''}",
                        "board": n, "win_length": k, "sims_per_move": S, "games_per_gpu": B, "engines_per_gpu": a.engines, "parallelism": f"games sharded x{world}" + (" (ranks sharing GPUs, gloo rehearsal)" if share else "")},
             "per_gpu_node_expansions_per_sec": exp_all / dt / world,
             "simulations_per_sec": sims_all / dt, "plies_per_sec": plies_all / dt,
