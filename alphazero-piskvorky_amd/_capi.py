@@ -27,7 +27,7 @@ AZ_MODEL_PLAIN, AZ_MODEL_RESNET = 0, 1
 EXPORTS = [
     "az_create", "az_destroy", "az_last_error", "az_load_weights", "az_load_weights_resnet", "az_net_eval", "az_search", "az_selfplay",
     "az_selfplay_begin", "az_selfplay_step", "az_selfplay_end", "az_selfplay_games", "az_selfplay_records", "az_record_bytes", "az_selfplay_pack", "az_examples_from_packed",
-    "az_examples_gather", "az_arena", "az_rng_selfplay_tape", "az_rng_uniforms", "az_set_profiling", "az_set_subtree_reuse", "az_get_counters",
+    "az_examples_gather", "az_arena", "az_rules_replay", "az_rng_selfplay_tape", "az_rng_uniforms", "az_set_profiling", "az_set_subtree_reuse", "az_get_counters",
 ]
 
 
@@ -145,6 +145,7 @@ class Engine:
     def __init__(self, board_size, win_length, num_simulations, slots, c_puct=2.0, dirichlet_alpha=0.3,
                  dirichlet_weight=0.25, synthetic=False, device=0, log_table=None, model="plain"):
         self.n, self.k, self.S, self.slots = board_size, win_length, num_simulations, slots
+        self.device = int(device)
         if model not in ("plain", "resnet"):
             raise ValueError("model must be 'plain' or 'resnet'")
         self.model = model
@@ -270,13 +271,12 @@ class Engine:
                     "az_selfplay_records")
         return out
 
-    @staticmethod
-    def _torch_sync():
+    def _torch_sync(self):
         """The engine works on its own non-blocking HIP stream and synchronises it before every call returns; device
-        buffers handed in by the caller (torch tensors) must be complete on the caller's side too."""
+        buffers handed in by the caller (torch tensors on the engine's device) must be complete on the caller's side too."""
         import torch
         if torch.cuda.is_available() and torch.cuda.is_initialized():
-            torch.cuda.current_stream().synchronize()
+            torch.cuda.current_stream(self.device).synchronize()
 
     def pack_into(self, dev_ptr):
         self._torch_sync()
@@ -293,6 +293,19 @@ class Engine:
         self._check(lib().az_examples_gather(self.h, C.c_void_p(packed_ptr), C.c_void_p(idx_ptr), C.c_void_p(sym_ptr),
                                              int(count), int(reference_pi), C.c_void_p(states_ptr), C.c_void_p(pis_ptr),
                                              C.c_void_p(z_ptr)), "az_examples_gather")
+
+    # ---- rules ----
+    def rules_replay(self, actions):
+        """Gomoku rules on the device for whole action lists (az_rules_replay): actions [games][max_len] int16, -1 padded."""
+        acts = np.ascontiguousarray(actions, np.int16)
+        if acts.ndim == 1:
+            acts = acts.reshape(1, -1)
+        G, L = acts.shape
+        term = np.zeros((G, max(L, 1)), np.uint8); boards = np.zeros((G, self.nn), np.uint8)
+        players = np.zeros(G, np.int32); results = np.zeros(G, np.int32); bad = np.zeros(G, np.int32)
+        self._check(lib().az_rules_replay(self.h, G, L, _p(acts), _p(term), _p(boards), _p(players), _p(results), _p(bad)),
+                    "az_rules_replay")
+        return dict(term_before=term[:, :L].astype(bool), boards=boards, players=players, results=results, first_illegal=bad)
 
     # ---- arena ----
     def arena(self, num_games, seed0=0, temperature_table=None, u_tape=None):

@@ -119,6 +119,25 @@ static int fail(az_engine *e, int code, const char *fmt, ...)
             return fail(e, AZ_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_r), __FILE__, __LINE__); \
     } while (0)
 
+// The HIP current device is thread-local state the caller's framework (PyTorch) shares with this library: every entry
+// point selects the engine's device for its own duration and puts the caller's device back on return.
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t rc;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        rc = prev == dev ? hipSuccess : hipSetDevice(dev);
+        if (prev == dev) prev = -1;          // nothing to restore
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define DEVICE_GUARD(e)                                                                            \
+    DeviceGuard _guard((e)->cfg.device);                                                           \
+    if (_guard.rc != hipSuccess) return fail(e, AZ_ERR_HIP, "hipSetDevice(%d) failed: %s", (e)->cfg.device, hipGetErrorString(_guard.rc))
+
 static int dev_alloc(az_engine *e, DevBuf &b, size_t bytes, bool zero = true)
 {
     if (b.p && b.bytes >= bytes) {
@@ -213,17 +232,11 @@ static std::vector<float> pack_fc(const float *w, int nout, int kin)
 // ------------------------------------------------------------------------------------------------
 const SizeOps *az_size_ops(int n)
 {
-#ifdef AZ_ONLY_N          // experiment builds with a single board size
-#define AZ_OPS_CAT2(a, b) a##b
-#define AZ_OPS_CAT(a, b) AZ_OPS_CAT2(a, b)
-    return n == AZ_ONLY_N ? AZ_OPS_CAT(az_size_ops_, AZ_ONLY_N)() : nullptr;
-#endif
     switch (n) {
-    case 3: return az_size_ops_3();   case 4: return az_size_ops_4();   case 5: return az_size_ops_5();
-    case 6: return az_size_ops_6();   case 7: return az_size_ops_7();   case 8: return az_size_ops_8();
-    case 9: return az_size_ops_9();   case 10: return az_size_ops_10(); case 11: return az_size_ops_11();
-    case 12: return az_size_ops_12(); case 13: return az_size_ops_13(); case 14: return az_size_ops_14();
-    case 15: return az_size_ops_15();
+#define AZ_CASE(k) case k: return az_size_ops_##k ? az_size_ops_##k() : nullptr;
+    AZ_CASE(3) AZ_CASE(4) AZ_CASE(5) AZ_CASE(6) AZ_CASE(7) AZ_CASE(8) AZ_CASE(9) AZ_CASE(10) AZ_CASE(11) AZ_CASE(12)
+    AZ_CASE(13) AZ_CASE(14) AZ_CASE(15)
+#undef AZ_CASE
     default: return nullptr;
     }
 }
@@ -377,7 +390,8 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
         delete e;
         return fail(nullptr, AZ_ERR_INVALID, "board size %d is not built into this library", cfg->board_size);
     }
-    hipError_t hr = hipSetDevice(cfg->device);
+    DeviceGuard guard(cfg->device);          // the caller's current device is restored on return
+    hipError_t hr = guard.rc;
     // Own hardware queue per engine: the runtime multiplexes the streams of one priority level over a small pool of
     // hardware queues, so next to a framework that has already created streams (PyTorch's context) two engines can
     // land on one queue and stop overlapping (measured: episode 11.6 -> 15.3 s).  High-priority streams draw from
@@ -472,7 +486,7 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
 extern "C" void az_destroy(az_engine *e)
 {
     if (!e) return;
-    (void)hipSetDevice(e->cfg.device);
+    DeviceGuard guard(e->cfg.device);
     stop_tapes(e);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     DevBuf *all[] = {&e->board, &e->s_game, &e->s_ply, &e->s_player, &e->s_last, &e->s_status, &e->s_net, &e->edges,
@@ -500,7 +514,7 @@ extern "C" int az_load_weights(az_engine *e, int slot, const float *const *t)
     if (e->cfg.model != AZ_MODEL_PLAIN) return fail(e, AZ_ERR_INVALID, "az_load_weights: engine was created for the ResidualBlock model");
     for (int i = 0; i < 16; i++)
         if (!t[i]) return fail(e, AZ_ERR_INVALID, "az_load_weights: tensor %d is null", i);
-    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    DEVICE_GUARD(e);
     const int nn = e->nn;
     PackedNet &p = e->net[slot];
     int rc = AZ_OK;
@@ -532,7 +546,7 @@ extern "C" int az_load_weights_resnet(az_engine *e, int slot, const float *const
     if (e->cfg.model != AZ_MODEL_RESNET) return fail(e, AZ_ERR_INVALID, "az_load_weights_resnet: engine was created for the plain model");
     for (int i = 0; i < 24; i++)
         if (!t[i]) return fail(e, AZ_ERR_INVALID, "az_load_weights_resnet: tensor %d is null", i);
-    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    DEVICE_GUARD(e);
     const int nn = e->nn;
     PackedNet &p = e->net[slot];
     int rc = AZ_OK;
@@ -815,6 +829,7 @@ static int run_episode(az_engine *e, const EpisodeSpec &sp, az_counters *out)
     int rc = episode_begin(e, sp);
     if (!rc) rc = episode_plies(e, 1 << 30);
     if (!rc) rc = episode_end(e, out);
+    if (rc) { e->run.open = false; stop_tapes(e); }
     return rc;
 }
 
@@ -834,7 +849,8 @@ static int upload_T(az_engine *e, const double *table, bool arena)
 extern "C" int az_selfplay_begin(az_engine *e, const az_selfplay_args *a)
 {
     if (!e || !a || a->num_games < 1) return fail(e, AZ_ERR_INVALID, "az_selfplay: bad argument");
-    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    if (e->run.open) return fail(e, AZ_ERR_STATE, "az_selfplay_begin: an episode is already open (az_selfplay_end first)");
+    DEVICE_GUARD(e);
     const int nn = e->nn, G = a->num_games;
     int rc = ensure_episode_buffers(e, G, true);
     if (rc) return rc;
@@ -842,7 +858,10 @@ extern "C" int az_selfplay_begin(az_engine *e, const az_selfplay_args *a)
     // tapes: explicit, or numpy-compatible RandomState(seed0 + g) streams generated on the host cores
     const int plies = a->max_plies > 0 && a->max_plies < nn ? a->max_plies : nn;
     if (a->noise_tape && a->u_tape) {
-        if (a->tape_stride < e->tape_len && a->max_plies <= 0) return fail(e, AZ_ERR_INVALID, "tape_stride too small");
+        // the explicit tape must cover every ply the games can reach: off(plies) = sum_{m < plies} (nn - m) doubles per game
+        int64_t need = 0;
+        for (int m = 0; m < plies; m++) need += nn - m;
+        if (a->tape_stride < need) return fail(e, AZ_ERR_INVALID, "tape_stride %lld is shorter than the %lld doubles %d plies need", (long long)a->tape_stride, (long long)need, plies);
         HIPCHECK(e, hipMemcpy2DAsync(e->noise.p, (size_t)e->tape_len * 8, a->noise_tape, (size_t)a->tape_stride * 8,
                                      (size_t)std::min<int64_t>(a->tape_stride, e->tape_len) * 8, G, hipMemcpyHostToDevice, e->stream));
         HIPCHECK(e, hipMemcpyAsync(e->u.p, a->u_tape, (size_t)G * nn * 8, hipMemcpyHostToDevice, e->stream));
@@ -872,7 +891,7 @@ extern "C" int az_selfplay_begin(az_engine *e, const az_selfplay_args *a)
 extern "C" int az_selfplay_step(az_engine *e, int max_steps, int32_t *active_out, az_counters *progress)
 {
     if (!e || max_steps < 0) return fail(e, AZ_ERR_INVALID, "az_selfplay_step: bad argument");
-    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    DEVICE_GUARD(e);
     int rc = episode_plies(e, max_steps);
     if (rc) return rc;
     if (active_out) *active_out = e->run.active;
@@ -887,15 +906,21 @@ extern "C" int az_selfplay_step(az_engine *e, int max_steps, int32_t *active_out
 extern "C" int az_selfplay_end(az_engine *e, az_counters *out)
 {
     if (!e) return AZ_ERR_INVALID;
-    HIPCHECK(e, hipSetDevice(e->cfg.device));
-    return episode_end(e, out);
+    DEVICE_GUARD(e);
+    const int rc = episode_end(e, out);
+    if (rc) { e->run.open = false; stop_tapes(e); }      // a failed episode is closed too: the engine stays usable
+    return rc;
 }
 
 extern "C" int az_selfplay(az_engine *e, const az_selfplay_args *a, az_counters *out)
 {
+    if (!e) return AZ_ERR_INVALID;
+    if (e->run.open) return fail(e, AZ_ERR_STATE, "az_selfplay: an episode is already open (az_selfplay_end first)");
+    DEVICE_GUARD(e);
     int rc = az_selfplay_begin(e, a);
     if (!rc) rc = episode_plies(e, 1 << 30);
     if (!rc) rc = episode_end(e, out);
+    if (rc) { e->run.open = false; stop_tapes(e); }
     return rc;
 }
 
@@ -913,7 +938,7 @@ extern "C" int az_selfplay_records(az_engine *e, uint8_t *boards, uint8_t *mover
                                    float *pis, int32_t *visits, int8_t *z)
 {
     if (!e || !e->have_episode) return fail(e, AZ_ERR_STATE, "no episode has been run");
-    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    DEVICE_GUARD(e);
     const int nn = e->nn, G = e->episode_games;
     const size_t tot = (size_t)G * nn;
     std::vector<u64> pl(tot * 8);
@@ -954,7 +979,7 @@ extern "C" int64_t az_record_bytes(const az_engine *e) { return e ? record_bytes
 extern "C" int az_selfplay_pack(az_engine *e, void *packed_dev)
 {
     if (!e || !e->have_episode || !packed_dev) return fail(e, AZ_ERR_STATE, "az_selfplay_pack: no episode / null buffer");
-    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    DEVICE_GUARD(e);
     const int nn = e->nn;
     std::vector<int> src;
     for (int g = 0; g < e->episode_games; g++)
@@ -975,7 +1000,7 @@ extern "C" int az_examples_from_packed(az_engine *e, const void *packed_dev, int
     if (!e || !packed_dev || !states_dev || !pis_dev || !z_dev || records < 0) return fail(e, AZ_ERR_INVALID, "az_examples_from_packed: bad argument");
     if (aug != AZ_AUG_NONE && aug != AZ_AUG_REFERENCE4 && aug != AZ_AUG_DIHEDRAL8) return fail(e, AZ_ERR_INVALID, "aug must be 1, 4 or 8");
     if (records == 0) return AZ_OK;
-    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    DEVICE_GUARD(e);
     hipLaunchKernelGGL(k_examples, dim3((unsigned)records), dim3(256), 0, e->stream, (const unsigned char *)packed_dev,
                        records, e->n, record_bytes(e->nn), aug, states_dev, pis_dev, z_dev);
     HIPCHECK(e, hipStreamSynchronize(e->stream));
@@ -1000,7 +1025,8 @@ extern "C" int az_net_eval(az_engine *e, int slot, int count, const uint8_t *boa
 {
     if (!e || slot < 0 || slot > 1 || count < 0 || !boards || !players || !lasts) return fail(e, AZ_ERR_INVALID, "az_net_eval: bad argument");
     if (!e->net[slot].loaded) return fail(e, AZ_ERR_NO_WEIGHTS, "weights slot %d not loaded", slot);
-    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    if (e->run.open) return fail(e, AZ_ERR_STATE, "az_net_eval: a self-play episode is open on this engine");
+    DEVICE_GUARD(e);
     const int nn = e->nn, B = e->d.B;
     DevBuf dpol, dval;
     int rc = dev_alloc(e, dpol, (size_t)B * nn * 4);
@@ -1050,7 +1076,8 @@ extern "C" int az_search(az_engine *e, int slot, const uint8_t *board, int playe
                          float *prior)
 {
     if (!e || !board || (player != 1 && player != 2) || slot < 0 || slot > 1) return fail(e, AZ_ERR_INVALID, "az_search: bad argument");
-    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    if (e->run.open) return fail(e, AZ_ERR_STATE, "az_search: a self-play episode is open on this engine");
+    DEVICE_GUARD(e);
     const int nn = e->nn;
     int stones = 0;
     for (int j = 0; j < nn; j++) {
@@ -1111,7 +1138,8 @@ extern "C" int az_arena(az_engine *e, const az_arena_args *a, az_arena_result *o
                         int32_t *nply)
 {
     if (!e || !a || a->num_games < 1) return fail(e, AZ_ERR_INVALID, "az_arena: bad argument");
-    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    if (e->run.open) return fail(e, AZ_ERR_STATE, "az_arena: a self-play episode is open on this engine");
+    DEVICE_GUARD(e);
     const int nn = e->nn, G = a->num_games;
     int rc = ensure_episode_buffers(e, G, false);
     if (rc) return rc;
@@ -1144,6 +1172,43 @@ extern "C" int az_arena(az_engine *e, const az_arena_args *a, az_arena_result *o
     return AZ_OK;
 }
 
+extern "C" int az_rules_replay(az_engine *e, int games, int max_len, const int16_t *actions, uint8_t *term_before,
+                               uint8_t *boards, int32_t *players, int32_t *results, int32_t *first_illegal)
+{
+    if (!e || games < 0 || max_len < 0 || !actions || !boards || !players || !results || !first_illegal)
+        return fail(e, AZ_ERR_INVALID, "az_rules_replay: bad argument");
+    if (games == 0) return AZ_OK;
+    DEVICE_GUARD(e);
+    const size_t G = (size_t)games, L = (size_t)(max_len > 0 ? max_len : 1), nn = (size_t)e->nn;
+    DevBuf da, dt, db, dp, dr, ds;
+    int rc = dev_alloc(e, da, G * L * 2, true);
+    if (!rc) rc = dev_alloc(e, dt, G * L, true);
+    if (!rc) rc = dev_alloc(e, db, G * nn, false);
+    if (!rc) rc = dev_alloc(e, dp, G * 4, false);
+    if (!rc) rc = dev_alloc(e, dr, G * 4, false);
+    if (!rc) rc = dev_alloc(e, ds, G * 4, false);
+    hipError_t hr = hipSuccess;
+    if (!rc) {
+        if (max_len > 0) hr = az_memcpy(e->stream, da.p, actions, G * L * 2, hipMemcpyHostToDevice);
+        else hr = hipMemsetAsync(da.p, 0xFF, G * L * 2, e->stream);
+        if (hr == hipSuccess) {
+            hipLaunchKernelGGL(k_rules_replay, dim3((games + 63) / 64), dim3(64), 0, e->stream, e->n, e->cfg.win_length, games,
+                               (int)L, (const short *)da.p, term_before ? (unsigned char *)dt.p : nullptr, (unsigned char *)db.p,
+                               (int *)dp.p, (int *)dr.p, (int *)ds.p);
+            hr = hipStreamSynchronize(e->stream);
+        }
+        if (hr == hipSuccess) hr = hipGetLastError();
+        if (hr == hipSuccess && term_before && max_len > 0) hr = az_memcpy(e->stream, term_before, dt.p, G * L, hipMemcpyDeviceToHost);
+        if (hr == hipSuccess) hr = az_memcpy(e->stream, boards, db.p, G * nn, hipMemcpyDeviceToHost);
+        if (hr == hipSuccess) hr = az_memcpy(e->stream, players, dp.p, G * 4, hipMemcpyDeviceToHost);
+        if (hr == hipSuccess) hr = az_memcpy(e->stream, results, dr.p, G * 4, hipMemcpyDeviceToHost);
+        if (hr == hipSuccess) hr = az_memcpy(e->stream, first_illegal, ds.p, G * 4, hipMemcpyDeviceToHost);
+        if (hr != hipSuccess) rc = fail(e, AZ_ERR_HIP, "az_rules_replay: %s", hipGetErrorString(hr));
+    }
+    dev_free(da); dev_free(dt); dev_free(db); dev_free(dp); dev_free(dr); dev_free(ds);
+    return rc;
+}
+
 // diagnostic builds (-DAZ_STAMPS): per-workgroup phase stamps of the last k_trunk launch, 16 u64 per workgroup
 extern "C" int az_debug_stamps(az_engine *e, unsigned long long *out, int max_groups)
 {
@@ -1160,7 +1225,7 @@ extern "C" int az_examples_gather(az_engine *e, const void *packed_dev, const in
     if (!e || !packed_dev || !idx_dev || !sym_dev || !states_dev || !pis_dev || !z_dev || count < 0)
         return fail(e, AZ_ERR_INVALID, "az_examples_gather: bad argument");
     if (count == 0) return AZ_OK;
-    HIPCHECK(e, hipSetDevice(e->cfg.device));
+    DEVICE_GUARD(e);
     hipLaunchKernelGGL(k_examples_gather, dim3((unsigned)count), dim3(256), 0, e->stream, (const unsigned char *)packed_dev,
                        (const long long *)idx_dev, (const int *)sym_dev, count, e->n, record_bytes(e->nn), reference_pi,
                        states_dev, pis_dev, z_dev);

@@ -26,6 +26,7 @@ struct SizeOps {
 };
 
 const SizeOps *az_size_ops(int n);     // nullptr for unsupported sizes
-#define AZ_DECL_OPS(n) const SizeOps *az_size_ops_##n();
+// weak: a development build may leave sizes out (make SIZES="5 9 15"); az_size_ops then returns nullptr for them
+#define AZ_DECL_OPS(n) const SizeOps *az_size_ops_##n() __attribute__((weak));
 AZ_DECL_OPS(3) AZ_DECL_OPS(4) AZ_DECL_OPS(5) AZ_DECL_OPS(6) AZ_DECL_OPS(7) AZ_DECL_OPS(8) AZ_DECL_OPS(9)
 AZ_DECL_OPS(10) AZ_DECL_OPS(11) AZ_DECL_OPS(12) AZ_DECL_OPS(13) AZ_DECL_OPS(14) AZ_DECL_OPS(15)

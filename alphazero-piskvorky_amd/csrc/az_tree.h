@@ -658,6 +658,36 @@ __global__ __launch_bounds__(1024) void k_refill(DevState d)
     if (tid == 0) { *d.next_game = base_s; *d.active = active_s; }
 }
 
+// az_rules_replay: Gomoku.apply_action / is_terminal / get_game_result (games.py:64-82,133-179) for whole action lists,
+// one thread per game, with the bit-plane helpers the search kernels use (pl_set, wins_through, pl_count).  The winner is
+// sticky like the reference's cached `winner` that clone() copies (games.py:140-141,206).
+__global__ void k_rules_replay(int n, int k, int games, int max_len, const short *actions, unsigned char *term_before,
+                               unsigned char *boards, int *players, int *results, int *status)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= games) return;
+    const int nn = n * n;
+    Plane X{}, O{};
+    int pl = 1, res = 0, bad = -1;
+    for (int i = 0; i < max_len; i++) {
+        const int a = actions[(size_t)g * max_len + i];
+        if (a < 0) break;
+        if (term_before) term_before[(size_t)g * max_len + i] = res != 0;
+        if (a >= nn || pl_get(X, a) || pl_get(O, a)) { bad = i; break; }       // games.py:76-77 ValueError("Invalid move")
+        Plane &mine = pl == 1 ? X : O;
+        pl_set(mine, a);
+        if (res == 0) {
+            if (wins_through(mine, a, n, k)) res = pl;
+            else if (pl_count(X) + pl_count(O) == nn) res = 3;
+        }
+        pl = 3 - pl;
+    }
+    for (int j = 0; j < nn; j++) boards[(size_t)g * nn + j] = pl_get(X, j) ? 1 : (pl_get(O, j) ? 2 : 0);
+    players[g] = pl;
+    results[g] = res;
+    status[g] = bad;
+}
+
 // custom start position for az_search: slot 0 gets the given state
 __global__ void k_set_position(DevState d, int slot, int game, int player, int last, int ply)
 {

@@ -9,6 +9,14 @@ from . import constants as _c
 from .net import GomokuNet
 
 
+def save_state_dict_atomic(state_dict, path):
+    """Write to a temporary name in the same directory, then rename: a reader that lists the directory never sees a
+    half-written checkpoint."""
+    tmp = f"{path}.tmp{os.getpid()}"
+    torch.save(state_dict, tmp)
+    os.replace(tmp, path)
+
+
 class ModelLoader:
     def __init__(self, model_dir=None, net_class=GomokuNet):
         self.model_dir = model_dir or _c.MODEL_DIR
@@ -20,7 +28,7 @@ class ModelLoader:
         net = self.net_class()
         if self.best_path is None:
             path = os.path.join(self.model_dir, f"model_{datetime.now().strftime('%Y%m%d_%H%M%S')}.pt")
-            torch.save(net.state_dict(), path)                        # model_loader.py:29-35
+            save_state_dict_atomic(net.state_dict(), path)            # model_loader.py:29-35
             self.best_path = path
             return net.float()
         net.load_state_dict(torch.load(self.best_path, map_location="cpu", weights_only=True))

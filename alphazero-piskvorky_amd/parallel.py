@@ -2,9 +2,9 @@
 
 Games never interact (self_play.py:41-73), so ranks play disjoint game ids with no data-path
 collective; the only exchange is at episode end: an all-gather of per-rank record counts, then an
-all-gather of the packed (planes, last move, pi, z) records padded to the largest count -- RCCL over
-xGMI when the process group is "nccl", gloo on CPU in the tests.  This replaces result_queue.put/get
-(self_play.py:73,140).
+all-gather -- or, for the reference's single trainer, a gather to one rank -- of the packed (planes, last
+move, pi, z) records padded to the largest count: RCCL over xGMI when the process group is "nccl", gloo
+on CPU in the tests.  This replaces result_queue.put/get (self_play.py:73,140).
 """
 import numpy as np
 import torch
@@ -15,12 +15,26 @@ def shard_games(num_games, rank, world):
     return list(range(rank, num_games, world))
 
 
-def all_gather_packed(packed, count, record_bytes):
-    """packed: uint8 tensor [count*record_bytes] on this rank's device.  Returns (list of per-rank uint8 tensors, counts)."""
+def _dist_on(force):
+    """True when collectives must run: a process group exists and has more than one rank -- or `force`, which drives a
+    one-rank group through the very same collective calls (how the RCCL branch is exercised on a single GPU)."""
     import torch.distributed as td
-    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+    return td.is_available() and td.is_initialized() and (td.get_world_size() > 1 or force)
+
+
+def rank_world():
+    import torch.distributed as td
+    return (td.get_rank(), td.get_world_size()) if td.is_available() and td.is_initialized() else (0, 1)
+
+
+def all_gather_packed(packed, count, record_bytes, dst=None, force=False):
+    """packed: uint8 tensor [count*record_bytes] on this rank's device.  Returns (list of per-rank uint8 tensors, counts).
+    dst=None: all-gather, every rank receives every rank's records.  dst=r: gather to rank r only (the reference has a
+    single trainer, train.py:95-104); the other ranks get an empty list of parts and the counts."""
+    import torch.distributed as td
+    if not _dist_on(force):
         return [packed[: count * record_bytes]], [int(count)]
-    world = td.get_world_size()
+    world, rank = td.get_world_size(), td.get_rank()
     dev = packed.device
     cnt = torch.tensor([count], dtype=torch.int64, device=dev)
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
@@ -29,14 +43,20 @@ def all_gather_packed(packed, count, record_bytes):
     mx = max(max(counts), 1)
     buf = torch.zeros(mx * record_bytes, dtype=torch.uint8, device=dev)
     buf[: count * record_bytes] = packed[: count * record_bytes]
-    outs = [torch.empty_like(buf) for _ in range(world)]
-    td.all_gather(outs, buf)
+    if dst is None:
+        outs = [torch.empty_like(buf) for _ in range(world)]
+        td.all_gather(outs, buf)
+    else:
+        outs = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+        td.gather(buf, gather_list=outs, dst=dst)
+        if rank != dst:
+            return [], counts
     return [o[: c * record_bytes] for o, c in zip(outs, counts)], counts
 
 
-def gather_packed_records(engine, device):
+def gather_packed_records(engine, device, dst=None, force=False):
     """Pack this rank's episode records on the device and exchange them.  Returns (uint8 tensor of all records
-    in rank order, per-rank counts)."""
+    in rank order -- empty on the ranks a gather-to-root leaves out --, per-rank counts)."""
     import torch.distributed as td
     count = engine.last_records
     packed = torch.zeros(max(count, 1) * engine.record_bytes, dtype=torch.uint8, device=device)
@@ -44,7 +64,9 @@ def gather_packed_records(engine, device):
         engine.pack_into(packed.data_ptr())
     # RCCL moves device buffers directly; with a gloo group (CPU tests, shared-GPU rehearsal) stage through the host
     host_xchg = td.is_available() and td.is_initialized() and td.get_backend() != "nccl" and packed.device.type != "cpu"
-    parts, counts = all_gather_packed(packed.cpu() if host_xchg else packed, count, engine.record_bytes)
+    parts, counts = all_gather_packed(packed.cpu() if host_xchg else packed, count, engine.record_bytes, dst=dst, force=force)
+    if not parts:
+        return torch.zeros(0, dtype=torch.uint8, device=device), counts
     out = torch.cat(parts) if len(parts) > 1 else parts[0]
     return (out.to(device) if host_xchg else out), counts
 
@@ -59,10 +81,10 @@ def arena_block(num_games, rank, world):
     return lo, min(lo + per, num_games)
 
 
-def all_reduce_tally(wins, losses, draws, device):
+def all_reduce_tally(wins, losses, draws, device, force=False):
     """Arena tally exchange: sum of three integers over the ranks (RCCL with an nccl group, gloo otherwise)."""
     import torch.distributed as td
-    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+    if not _dist_on(force):
         return int(wins), int(losses), int(draws)
     on_dev = td.get_backend() == "nccl"
     t = torch.tensor([wins, losses, draws], dtype=torch.int64, device=device if on_dev else "cpu")
@@ -71,10 +93,10 @@ def all_reduce_tally(wins, losses, draws, device):
     return w, l, d
 
 
-def broadcast_seed(seed, device):
+def broadcast_seed(seed, device, force=False):
     """Rank 0's seed for everybody (the reference is unseeded; ranks must still agree on the episode's game seeds)."""
     import torch.distributed as td
-    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+    if not _dist_on(force):
         return int(seed)
     on_dev = td.get_backend() == "nccl"
     t = torch.tensor([int(seed)], dtype=torch.int64, device=device if on_dev else "cpu")
@@ -82,12 +104,12 @@ def broadcast_seed(seed, device):
     return int(t.item())
 
 
-def broadcast_module_(module, src=0):
+def broadcast_module_(module, src=0, force=False):
     """Rank `src`'s parameters and buffers for everybody, in place (the weight exchange after the optimizer
     steps, so that every rank searches with the same net in the next episode).  RCCL moves the device tensors directly;
     with a gloo group they are staged through the host."""
     import torch.distributed as td
-    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+    if not _dist_on(force):
         return module
     direct = td.get_backend() == "nccl"
     with torch.no_grad():

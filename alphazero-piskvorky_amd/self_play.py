@@ -21,7 +21,7 @@ class SelfPlayManager:
     def __init__(self, controller, device, mcts_params: dict = None,
                  temperature_schedule: Callable[[int], float] = default_temperature_schedule,
                  concurrent_games: int = None, augmentation: int = AZ_AUG_REFERENCE4, seed: int = None,
-                 engines_per_gpu: int = None, subtree_reuse: bool = False):
+                 engines_per_gpu: int = None, subtree_reuse: bool = False, gather_to: int = None):
         self.controller = controller
         self.device = device
         self.mcts_params = mcts_params or {"num_simulations": 100}
@@ -31,6 +31,7 @@ class SelfPlayManager:
         self.seed = seed
         self.engines_per_gpu = engines_per_gpu or _c.ENGINES_PER_GPU
         self.subtree_reuse = subtree_reuse    # opt-in search upgrade (mcts.py:17-22 TODO); off = the reference's fresh root every move
+        self.gather_to = gather_to            # multi-rank: None = every rank receives all records (all-gather); r = only rank r does
         self.last_counters = None
         self._engine = None
 
@@ -67,10 +68,9 @@ class SelfPlayManager:
         """The same episode, but the result stays on the device as packed records (one per position, all ranks'
         records after the exchange): (uint8 tensor, record count, engine, device, n).  Feed it to
         device_replay.DeviceReplayBuffer.extend_packed to train without materialising Python tuples."""
-        import torch.distributed as td
         n = self.controller.net.board_size
         k = min(_c.WIN_LENGTH, n)
-        rank, world = (td.get_rank(), td.get_world_size()) if td.is_available() and td.is_initialized() else (0, 1)
+        rank, world = parallel.rank_world()
         per = (num_games + world - 1) // world
         lo, hi = min(rank * per, num_games), min((rank + 1) * per, num_games)
         mine = hi - lo
@@ -86,5 +86,6 @@ class SelfPlayManager:
             self.last_counters = eng.selfplay(mine, seed0=seed0 + lo, temperature_table=T)
         else:
             eng.last_records = 0
-        packed, counts = parallel.gather_packed_records(eng, dev)
-        return packed, int(sum(counts)), eng, dev, n
+        packed, counts = parallel.gather_packed_records(eng, dev, dst=self.gather_to)
+        total = int(sum(counts)) if (self.gather_to is None or rank == self.gather_to) else 0
+        return packed, total, eng, dev, n

@@ -31,10 +31,14 @@ def run(episodes, games, sims, eval_games, device="cuda:0", seed=0, model_dir=No
     in a device ring, batches unpacked + augmented by az_examples_gather) instead of materialising Python tuples."""
     torch.manual_seed(seed)
     n = C.BOARD_SIZE
+    rank, world = parallel.rank_world()
     candidate = NeuralNetworkController(GomokuNet(board_size=n), device=device)
+    parallel.broadcast_module_(candidate.net)            # every rank starts from rank 0's initialisation
     model_dir = model_dir or tempfile.mkdtemp(prefix="az_models_")
+    # multi-rank: every rank plays its shard of the games; the records go to rank 0 only (the reference has one trainer,
+    # train.py:95-104), rank 0 takes the optimizer steps and its weights are broadcast; only rank 0 writes model_dir
     manager = SelfPlayManager(candidate, device, mcts_params={"num_simulations": sims, "c_puct": C.SELF_PLAY_EXPLORATION_CONSTANT},
-                              seed=seed, subtree_reuse=subtree_reuse)
+                              seed=seed, subtree_reuse=subtree_reuse, gather_to=0 if world > 1 else None)
     evaluator = ModelEvaluator(game_class=Gomoku, print_games=False, device=device, seed=seed)
     promoter = ModelPromoter(model_dir, evaluator, lambda: GomokuNet(board_size=n), device, threshold=PROMOTION_THRESHOLD)
     buffer = ReplayBuffer(capacity=C.BUFFER_CAPACITY)
@@ -45,28 +49,34 @@ def run(episodes, games, sims, eval_games, device="cuda:0", seed=0, model_dir=No
     try:
         for ep in range(episodes):
             t0 = time.perf_counter()
-            manager.seed = seed + 1_000_003 * ep
+            # disjoint seed ranges per episode and per use: game g of the episode's self-play draws from
+            # RandomState(base + g), arena game g from RandomState(base + 500_000 + g)
+            base = seed + 1_000_003 * ep
+            manager.seed = base
             losses = []
             if device_replay:
                 from .device_replay import DeviceReplayBuffer
                 packed, records, eng, dev, _ = manager.generate_packed(games)
-                if ring is None:
-                    ring = DeviceReplayBuffer(eng, capacity=C.BUFFER_CAPACITY, aug=manager.augmentation, device=dev, seed=seed)
-                ring.extend_packed(packed, records)
                 data = range(records * manager.augmentation)
-                for _ in range(C.BATCHES_PER_EPISODE):
-                    losses.append(candidate.train_tensors(*ring.sample_batch(C.BATCH_SIZE), epochs=C.NUM_EPOCHS))
+                if rank == 0:
+                    if ring is None:
+                        ring = DeviceReplayBuffer(eng, capacity=C.BUFFER_CAPACITY, aug=manager.augmentation, device=dev, seed=seed)
+                    ring.extend_packed(packed, records)
+                    for _ in range(C.BATCHES_PER_EPISODE):
+                        losses.append(candidate.train_tensors(*ring.sample_batch(C.BATCH_SIZE), epochs=C.NUM_EPOCHS))
             else:
                 data = manager.generate_self_play(num_games=games, num_workers=C.NUM_WORKERS)   # train.py:89-92
-                buffer.extend(data)                                                              # train.py:95
-                for _ in range(C.BATCHES_PER_EPISODE):                                           # train.py:100-104
-                    losses.append(candidate.train(buffer.sample_batch(C.BATCH_SIZE), epochs=C.NUM_EPOCHS))
+                if rank == 0:
+                    buffer.extend(data)                                                          # train.py:95
+                    for _ in range(C.BATCHES_PER_EPISODE):                                       # train.py:100-104
+                        losses.append(candidate.train(buffer.sample_batch(C.BATCH_SIZE), epochs=C.NUM_EPOCHS))
             parallel.broadcast_module_(candidate.net)          # multi-rank: everybody continues with rank 0's weights
-            evaluator.seed = seed + 7 * ep
+            evaluator.seed = base + 500_000
             win_rate, metrics, promoted = promoter.evaluate_and_maybe_promote(candidate, num_games=eval_games)   # train.py:114-119
-            history.append(dict(metrics, episode=ep, examples=len(data), loss=losses[-1].get("loss"),
+            loss = losses[-1].get("loss") if losses else None
+            history.append(dict(metrics, episode=ep, examples=len(data), loss=loss,
                                 promoted=promoted, seconds=time.perf_counter() - t0))
-            log(f"[train] episode {ep}: {len(data)} examples, loss {losses[-1].get('loss'):.4f}, "
+            log(f"[train] episode {ep}: {len(data)} examples, loss {'n/a' if loss is None else format(loss, '.4f')}, "
                 f"arena {metrics['wins']}/{metrics['losses']}/{metrics['draws']} -> {win_rate:.2%}"
                 f"{' (promoted)' if promoted else ''}, {history[-1]['seconds']:.1f}s")
     finally:
@@ -86,7 +96,7 @@ def main():
     ap.add_argument("--device-replay", action="store_true", help="keep examples on the GPU (packed ring + on-device batch unpacking)")
     a = ap.parse_args()
     # one process per GPU under torch.distributed.run: games and arena games are sharded over the ranks (self_play.py,
-    # evaluator.py), the examples are all-gathered, every rank takes the same optimizer steps' result from rank 0
+    # evaluator.py), the examples are gathered to rank 0, which trains, writes the checkpoints and broadcasts the weights
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         import torch.distributed as td
@@ -94,8 +104,6 @@ def main():
         torch.cuda.set_device(local)
         td.init_process_group("nccl", device_id=torch.device("cuda", local))
         a.device = f"cuda:{local}"
-        if td.get_rank() != 0 and a.model_dir is None:
-            a.model_dir = tempfile.mkdtemp(prefix=f"az_models_rank{td.get_rank()}_")
     run(a.episodes, a.games, a.sims, a.eval_games, a.device, model_dir=a.model_dir, device_replay=a.device_replay,
         subtree_reuse=a.subtree_reuse)
     if world > 1:

@@ -97,7 +97,9 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    dist = world > 1
+    # launched by torch.distributed.run (the driver's N > 1 launch line, also valid with one rank): collectives go through
+    # the process group -- RCCL -- whatever the world size; plain `python bench.py` has no process group
+    dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     ndev = torch.cuda.device_count()
     share = dist and ndev < world          # rehearsal on a box with fewer GPUs than ranks: ranks share devices, gloo collectives
     local = local % max(ndev, 1)
@@ -169,7 +171,7 @@ def main():
         torch.cuda.synchronize()
         ep_local = cend["seconds"]
         tg0 = time.perf_counter()
-        packed, counts = parallel.gather_packed_records(eng, dev)
+        packed, counts = parallel.gather_packed_records(eng, dev, force=dist)
         torch.cuda.synchronize()
         tg = time.perf_counter() - tg0
         ep = torch.tensor([ep_local, tg], dtype=torch.float64, device=cdev)
@@ -236,6 +238,7 @@ def main():
             "metric": "mcts_node_expansions_per_sec", "value": exp_all / dt, "unit": "node-expansions/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / max(a.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "collectives": (td.get_backend() if dist else None),
             "config": {"workload": f"{n}x{n} / {k}-in-a-row self-play, {B} concurrent games per GPU, {S} sims/move "
                                    f"{'(BASELINE.json configs[3] per-GPU shard)' if (n, k, S, B, a.model) == (15, 5, 400, 1024, 'plain') else '(custom)'}, {'GomokuNet' if a.model == 'plain' else 'ResidualBlock net'} random-init weights, numpy-compatible RNG tapes{', SUBTREE REUSE ON (not the reference algorithm)' if a.subtree_reuse else ''}",
                        "board": n, "win_length": k, "sims_per_move": S, "games_per_gpu": B, "engines_per_gpu": a.engines, "parallelism": f"games sharded x{world}" + (" (ranks sharing GPUs, gloo rehearsal)" if share else "")},

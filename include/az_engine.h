@@ -188,6 +188,17 @@ typedef struct { int32_t wins, losses, draws, total; double win_rate; } az_arena
 int az_arena(az_engine *e, const az_arena_args *args, az_arena_result *out, int32_t *results, int16_t *actions,
              int32_t *nply);
 
+/* ---- rules only: Gomoku.apply_action / is_terminal / get_game_result (games.py:64-82,133-179) ----
+ * Replays `games` action lists (actions[g][max_len], r*n+c, -1 = end of list) from the empty board with X to move, on the
+ * device, with the same bit-plane win test the search kernels use.  Like the reference, apply_action does not look at
+ * the terminal flag (a list may continue past the end of the game; the winner stays the first one, games.py:140-141).
+ * Outputs (term_before may be NULL): term_before[g][i] = is_terminal() before move i; boards[g][n*n] final cells
+ * (0 empty, 1 X, 2 O); players[g] = side to move afterwards; results[g] = AZ_RES_*; first_illegal[g] = index of the
+ * first illegal action of the list (occupied cell or out of range: games.py:76-77 ValueError), -1 if none -- the replay
+ * of that game stops there. */
+int az_rules_replay(az_engine *e, int games, int max_len, const int16_t *actions, uint8_t *term_before, uint8_t *boards,
+                    int32_t *players, int32_t *results, int32_t *first_illegal);
+
 /* ---- host-side numpy-compatible RNG (legacy MT19937 RandomState; mcts.py:114,177) ---- */
 int az_rng_selfplay_tape(uint64_t seed, int board_size, double alpha, int max_plies, double *noise, double *u);
 int az_rng_uniforms(uint64_t seed, int count, double *u);

@@ -18,6 +18,7 @@ Fixture families:
   G5 augment.npz            SelfPlayManager._augment_symmetries on an asymmetric input
   G6 arena_5x4.npz          ModelEvaluator.evaluate between two 5x5 checkpoints, per-game seeds
   G7 zlabels.json           the z truth table of alphazero/tests/tests.py:11-22
+  G4-full netgame_full_{n}x{k}.npz  real-net plies at the BASELINE search sizes: 15x15/400 sims (7 plies), 9x9/200 sims (24 plies)
 """
 import json
 import os
@@ -416,8 +417,91 @@ def worker(n, k):
                    "versions": {"numpy": np.__version__, "torch": torch.__version__, "python": sys.version.split()[0]}}, f, indent=1)
 
 
+# --------------------------------------------------------------------------
+# G4-full: the real net at the BASELINE workloads' search sizes -- 15x15 / 400 simulations (configs[3]) and
+# 9x9 / 200 simulations (configs[2]) -- played by the Python reference itself.  Kept apart from worker() so that
+# re-running it leaves the other fixtures untouched:  python tests/golden/make_golden.py full
+# --------------------------------------------------------------------------
+def worker_full(n, k):
+    sys.path.insert(0, REF)
+    import constants
+    constants.BOARD_SIZE, constants.WIN_LENGTH = n, k
+    import torch
+    torch.set_num_threads(1)
+    import mcts as mcts_mod
+    from games import Gomoku
+    from mcts import MCTS
+    from net import GomokuNet
+    from controller import NeuralNetworkController, make_policy_value_fn
+    from self_play import default_temperature_schedule
+    X, O, DRAW = constants.X, constants.O, constants.DRAW
+    nn = n * n
+    res_code = {None: 0, X: 1, O: 2, DRAW: 3}
+
+    def abs_board(state):
+        b = np.zeros(nn, dtype=np.uint8)
+        for r in range(n):
+            for q in range(n):
+                s = state.board[r][q]
+                if s is not None:
+                    b[r * n + q] = 1 if s == X else 2
+        return b
+
+    class Capture:
+        root = None
+    OrigNode = mcts_mod.Node
+    class RecNode(OrigNode):
+        def __init__(self, state, parent=None, prior=1.0):
+            super().__init__(state, parent, prior)
+            if parent is None:
+                Capture.root = self
+    mcts_mod.Node = RecNode
+
+    S = {9: 200, 15: 400}[n]
+    maxply = {9: 24, 15: 7}[n]
+    seed = 1900
+    net = GomokuNet(device="cpu")
+    net.load_state_dict({kk: torch.tensor(v) for kk, v in build_weights(n).items()})
+    net.eval()
+    pvf = make_policy_value_fn(NeuralNetworkController(net, device="cpu"))
+    np.random.seed(seed)
+    m = MCTS(pvf, num_simulations=S, c_puct=2.0)
+    s = Gomoku(); mv = 0; recs = []; hist = []
+    while not s.is_terminal() and mv < maxply:
+        T = default_temperature_schedule(mv)
+        pi, a = m.run(s, temperature=T, add_root_noise=True)
+        root = Capture.root
+        N = np.zeros(nn, dtype=np.int32); W = np.zeros(nn, dtype=np.float64); P = np.zeros(nn, dtype=np.float32)
+        for (r, c), ch in root.children.items():
+            N[r * n + c] = ch.N; W[r * n + c] = ch.W; P[r * n + c] = np.float32(ch.prior)
+        recs.append(dict(game=0, ply=mv, board=abs_board(s), player=1 if s.current_player == X else 2,
+                         last=-1 if s.last_action is None else s.last_action[0] * n + s.last_action[1],
+                         pi=pi.astype(np.float32).reshape(nn), N=N, W=W, P=P, action=a[0] * n + a[1], T=float(T)))
+        hist.append(s.current_player)
+        s = s.apply_action(a); mv += 1
+        print(f"[full {n}x{n}] ply {mv}", flush=True)
+    fin = s.get_game_result()
+    for j, pl in enumerate(hist):
+        recs[j]["z"] = 99 if fin is None else (0 if fin == DRAW else 1 if pl == fin else -1)
+    for r_ in recs:
+        r_["final"] = 255
+    recs[-1]["final"] = res_code[fin]
+    np.savez_compressed(
+        os.path.join(HERE, f"netgame_full_{n}x{k}.npz"), n=n, k=k, S=S, seed0=seed, maxply=maxply, weights="seeded",
+        **{key: np.array([c[key] for c in recs]) for key in recs[0]})
+
+
 if __name__ == "__main__":
-    if len(sys.argv) == 3:
+    if len(sys.argv) == 4 and sys.argv[3] == "full":
+        worker_full(int(sys.argv[1]), int(sys.argv[2]))
+    elif len(sys.argv) == 2 and sys.argv[1] == "full":
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(n), str(k), "full"], env=env, cwd="/tmp")
+                 for n, k in ((9, 5), (15, 5))]
+        rc = [p.wait() for p in procs]
+        print("done", rc)
+        sys.exit(max(rc))
+    elif len(sys.argv) == 3:
         worker(int(sys.argv[1]), int(sys.argv[2]))
     else:
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")

@@ -175,6 +175,31 @@ def test_full_size_15x15_400sims_episode_with_refill():
     eng.close()
 
 
+def test_full_size_9x9_4096_slots_200sims_episode_with_refill():
+    """BASELINE configs[2] end to end: 9x9 / 5-in-a-row, 4096 concurrent games (4 engines: two boards per trunk workgroup,
+    two rounds of workgroups per launch), 200 simulations, 4300 games so that slots are refilled; every game is replayed
+    with the oracle's rules, every record is checked, and a few complete games are compared with the oracle bit for bit."""
+    n, k, S, G = 9, 5, 200, 4300
+    sd = weights_from_fixture(n, "seeded")
+    eng = az.MultiEngine(n, k, S, 4096, engines=4, log_table=orc.numpy_log_table(S))
+    eng.load_weights(sd, 0)
+    c = eng.selfplay(G, seed0=1618)
+    rec = eng.records(); nply, res = eng.games()
+    eng.close()
+    assert c["games"] == G and c["plies"] == int(nply.sum()) and (nply >= 9).all()
+    assert c["simulations"] == S * c["plies"] and c["expansions"] + c["terminal_hits"] == c["simulations"]
+    _check_episode_invariants(n, k, S, rec, nply, res, G)
+    o = orc.Oracle(n, k, S); onet = orc.Net(n, sd)
+    starts = np.concatenate([[0], np.cumsum(nply)])
+    for g in (0, 1023, 2048, 4095, 4096, 4299):                               # first-round slots of every engine + refilled ones
+        noise, us = orc.selfplay_tape(1618 + g, n)
+        r = o.selfplay_game(onet, noise, us)
+        sl = slice(int(starts[g]), int(starts[g + 1]))
+        assert r["nply"] == int(nply[g]) and r["result"] == int(res[g])
+        for key in ("actions", "boards", "visits", "pis", "z"):
+            assert np.array_equal(rec[key][sl], r[key]), f"game {g}: {key} differs from the oracle"
+
+
 def test_generate_packed_feeds_the_device_replay_ring():
     import torch
     from alphazero_piskvorky_amd import net
@@ -243,14 +268,15 @@ def test_non_default_search_parameters(c_puct, alpha, w):
 def test_streamed_tapes_equal_bulk_tapes_with_refill_and_restart(monkeypatch):
     """The tape producer (waves of two plies streamed ahead of the games) against AZ_TAPE_STREAM=0 (every tape generated
     before the first move): many more games than slots, so refilled slots start late at ply 0 while the waves are far
-    ahead; also an episode abandoned mid-way (its producer must stop) and a max_plies cap shorter than one wave."""
+    ahead; also an episode ended mid-way (its producer must stop) and a max_plies cap shorter than one wave."""
     n, k, S, G = 5, 4, 12, 37
     out = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("AZ_TAPE_STREAM", mode)
         e = _engine(n, k, S, slots=5, synthetic=True)
         e.selfplay_begin(G, seed0=31337)
-        e.selfplay_step(3)                      # abandoned: the next begin replaces the episode and its producer
+        e.selfplay_step(3)
+        e.selfplay_end()                        # abandoned after 3 plies: its producer must stop before the next episode
         e.selfplay(G, seed0=31337)
         full = e.records(); nply, res = e.games()
         e.selfplay(G, seed0=31337, max_plies=1)
@@ -263,3 +289,45 @@ def test_streamed_tapes_equal_bulk_tapes_with_refill_and_restart(monkeypatch):
     for key in out["1"][3]:
         assert np.array_equal(out["1"][3][key], out["0"][3][key]), key
     assert len(out["1"][3]["actions"]) == G
+
+
+def test_calls_that_would_clobber_an_open_episode_are_rejected():
+    """az_search / az_net_eval / az_arena / a nested az_selfplay_begin between begin and end would overwrite the slot and
+    record state of the running episode: AZ_ERR_STATE, and the episode continues undisturbed."""
+    n, k, S, G = 5, 4, 20, 6
+    ref = _engine(n, k, S, slots=4, synthetic=True)
+    ref.selfplay(G, seed0=808)
+    want = ref.records()
+    ref.close()
+    e = _engine(n, k, S, slots=4, synthetic=True)
+    e.selfplay_begin(G, seed0=808)
+    e.selfplay_step(2)
+    board = np.zeros(n * n, np.uint8)
+    for call in (lambda: e.search(board, 1, -1, 1.0), lambda: e.arena(2, seed0=1), lambda: e.selfplay_begin(G, seed0=1),
+                 lambda: e.selfplay(G, seed0=1)):
+        with pytest.raises(az.AzError, match="-6"):
+            call()
+    active = 1
+    while active > 0:
+        active, _ = e.selfplay_step(64)
+    e.selfplay_end()
+    got = e.records()
+    for key in want:
+        assert np.array_equal(want[key], got[key]), key
+    e.close()
+
+
+def test_explicit_tape_shorter_than_the_plies_is_rejected():
+    n, k, S, G = 5, 4, 8, 2
+    nn = n * n
+    e = _engine(n, k, S, slots=2, synthetic=True)
+    full = sum(nn - m for m in range(nn))
+    three = sum(nn - m for m in range(3))
+    us = np.full((G, nn), 0.5)
+    with pytest.raises(az.AzError):
+        e.selfplay(G, noise_tape=np.full((G, full - 1), 0.1), u_tape=us)             # whole games need the whole tape
+    with pytest.raises(az.AzError):
+        e.selfplay(G, max_plies=3, noise_tape=np.full((G, three - 1), 0.1), u_tape=us)
+    c = e.selfplay(G, max_plies=3, noise_tape=np.full((G, three), 1.0 / nn), u_tape=us)   # exactly 3 plies of tape: accepted
+    assert c["plies"] == 3 * G
+    e.close()

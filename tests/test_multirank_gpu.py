@@ -92,3 +92,47 @@ def test_arena_two_ranks_equals_single_process(tmp_path):
     assert ref["total"] == 11
     for rank in (0, 1):
         assert json.load(open(multi + f".{rank}.json")) == ref
+
+
+TRAIN_WORKER = r'''
+import os, sys, json, torch
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as td
+td.init_process_group("gloo")
+from alphazero_piskvorky_amd import constants as C, train
+C.BOARD_SIZE, C.WIN_LENGTH = 5, 4
+C.BATCHES_PER_EPISODE, C.NUM_EPOCHS, C.BATCH_SIZE = 2, 1, 64
+hist = train.run(episodes=2, games=10, sims=16, eval_games=6, device="cuda:0", seed=3, model_dir=sys.argv[2], log=lambda *a: None)
+rank = td.get_rank()
+json.dump([{k: h[k] for k in ("wins", "losses", "draws", "total", "promoted", "examples")} for h in hist],
+          open(sys.argv[3] + f".{rank}.json", "w"))
+td.barrier(); td.destroy_process_group()
+'''
+
+
+def test_train_loop_two_ranks_shared_model_dir(tmp_path):
+    """The training loop under two ranks with ONE --model-dir: only rank 0 touches the directory (baseline created once,
+    promotions saved atomically), the baseline and the trained weights are broadcast, the records are gathered to rank 0,
+    and both ranks report the same arena tallies and promotion decisions."""
+    import json
+    import torch
+    script = tmp_path / "train_worker.py"
+    script.write_text(TRAIN_WORKER)
+    models = tmp_path / "models"
+    out = str(tmp_path / "hist")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29737", str(script), ROOT, str(models), out],
+                       env=env, timeout=600, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    h0, h1 = json.load(open(out + ".0.json")), json.load(open(out + ".1.json"))
+    assert len(h0) == 2 and all(h["total"] == 6 for h in h0)
+    for a, b in zip(h0, h1):
+        assert {k: a[k] for k in ("wins", "losses", "draws", "promoted")} == {k: b[k] for k in ("wins", "losses", "draws", "promoted")}
+        assert a["examples"] > 0 and b["examples"] == 0           # gather-to-root: rank 1 keeps no examples
+    files = sorted(f for f in os.listdir(models))
+    assert all(f.endswith(".pt") for f in files), files           # no temporary files left behind
+    assert len(files) == 1 + sum(h["promoted"] for h in h0)       # one baseline + one checkpoint per promotion
+    for f in files:
+        sd = torch.load(os.path.join(models, f), map_location="cpu", weights_only=True)
+        assert "conv1.weight" in sd

@@ -118,12 +118,17 @@ def test_net_forward_vs_torch(n):
             assert abs(P.sum() - 1.0) < 1e-5
 
 
-@pytest.mark.parametrize("n,k", SIZES)
-def test_real_net_games_teacher_forced(n, k):
+NETGAMES = ["netgame_5x4", "netgame_9x5", "netgame_15x5",
+            "netgame_full_9x5", "netgame_full_15x5"]     # G4-full: 9x9 / 200 sims (24 plies), 15x15 / 400 sims (7 plies)
+
+
+@pytest.mark.parametrize("fixture", NETGAMES)
+def test_real_net_games_teacher_forced(fixture):
     """G4: per ply, search from the reference's recorded position with the reference's RNG draws.
     Priors/values differ from torch in the last bits, so visit counts are compared with a small budget
     and must be identical whenever the chosen action matches (it must always match here)."""
-    z = load(f"netgame_{n}x{k}.npz")
+    z = load(fixture + ".npz")
+    n, k = int(z["n"]), int(z["k"])
     S = int(z["S"])
     o = orc.Oracle(n, k, S)
     net = orc.Net(n, weights_from_fixture(n, str(z["weights"])))

@@ -25,14 +25,14 @@ class FakeEngine:
         ctypes.memmove(ptr, buf.ctypes.data, buf.nbytes)
 
 
-def _worker(rank, world, port, counts, q):
+def _worker(rank, world, port, counts, q, dst=None):
     import sys
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     td.init_process_group("gloo", rank=rank, world_size=world)
     from alphazero_piskvorky_amd import parallel
     eng = FakeEngine(rank, counts[rank])
-    packed, got = parallel.gather_packed_records(eng, torch.device("cpu"))
+    packed, got = parallel.gather_packed_records(eng, torch.device("cpu"), dst=dst)
     q.put((rank, got, packed.numpy().copy()))
     td.barrier()
     td.destroy_process_group()
@@ -54,6 +54,29 @@ def test_gather_packed_records_world2_gloo(counts):
     for rank, got, packed in outs:
         assert list(got) == list(counts)
         assert np.array_equal(packed, expect), f"rank {rank} received a different record stream"
+
+
+@pytest.mark.parametrize("counts,dst", [((5, 3), 0), ((0, 4), 1), ((2, 0), 0)])
+def test_gather_to_root_world2_gloo(counts, dst):
+    """Gather to one rank (the reference's single trainer): the root holds every rank's records in rank order, the other
+    rank receives the counts only."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29100 + (os.getpid() % 500) + sum(counts) + dst
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, counts, q, dst)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    expect = np.concatenate([FakeEngine(r, counts[r]).payload() for r in range(2)])
+    for rank, got, packed in outs:
+        assert list(got) == list(counts)
+        if rank == dst:
+            assert np.array_equal(packed, expect)
+        else:
+            assert packed.size == 0
 
 
 def test_single_process_gather_is_identity():

@@ -107,3 +107,83 @@ def test_resnet_arena_and_shims():
     assert metrics["total"] == 4 and 0.0 <= wr <= 1.0
     out = a.train(data[:64], epochs=1)
     assert np.isfinite(out["loss"])
+
+
+def _host_threads():
+    import os
+    return max(1, min(16, os.cpu_count() or 1))
+
+
+def test_config4_resnet_15x15_800sims_complete_games_bit_exact_vs_oracle():
+    """BASELINE configs[4] at its workload: complete 15x15 / 5-in-a-row games, ResidualBlock net, 800 simulations per
+    move.  Every ply of every game is searched again by the oracle from the engine's recorded position with the same
+    tape (one search per host thread), and the recorded boards are the oracle-rules replay of the recorded moves, so by
+    induction the games equal the oracle's free-running games: visit counts, pi bit patterns, moves, outcomes, z."""
+    from concurrent.futures import ThreadPoolExecutor
+    n, k, S, G, seed0 = 15, 5, 800, 2, 4100
+    nn = n * n
+    sd = synthetic_resnet_state_dict(n)
+    e = az.Engine(n, k, S, G, model="resnet", log_table=orc.numpy_log_table(S))
+    e.load_weights(sd, 0)
+    c = e.selfplay(G, seed0=seed0)
+    rec = e.records(); nply, res = e.games()
+    e.close()
+    assert c["simulations"] == S * c["plies"] and c["expansions"] + c["terminal_hits"] == c["simulations"]
+    o = orc.Oracle(n, k, S)
+    onet = orc.Net(n, resnet_tensors=fold_resnet_state_dict(sd))
+    T = orc.selfplay_T_table(nn)
+    jobs = []
+    off = 0
+    for g in range(G):
+        L = int(nply[g])
+        assert L >= 9 and int(res[g]) in (1, 2, 3)
+        tape, us = orc.selfplay_tape(seed0 + g, n, maxply=L)
+        rc, term, board, pl, result = o.replay(rec["actions"][off:off + L])
+        assert rc == 0 and not term.any() and result == int(res[g])
+        want_z = np.array([0 if result == 3 else (1 if m == result else -1) for m in rec["movers"][off:off + L]])
+        assert np.array_equal(rec["z"][off:off + L], want_z)
+        noff = 0
+        for m in range(L):
+            _, _, bm, pm, _ = o.replay(rec["actions"][off:off + m])
+            assert np.array_equal(rec["boards"][off + m], bm) and int(rec["movers"][off + m]) == pm
+            jobs.append((off + m, bm, pm, int(rec["lasts"][off + m]), float(T[m]), tape[noff:noff + nn - m], float(us[m])))
+            noff += nn - m
+        off += L
+
+    def one(j):
+        ri, board, pl, last, temp, noise, u = j
+        r = o.search(onet, board, pl, last, temp, noise, u)
+        return ri, r
+
+    with ThreadPoolExecutor(_host_threads()) as ex:
+        for ri, r in ex.map(one, jobs):
+            assert np.array_equal(rec["visits"][ri], r["N"]), f"record {ri}: visit counts differ from the oracle"
+            assert np.array_equal(rec["pis"][ri], r["pi"]), f"record {ri}: pi differs bit-wise from the oracle"
+            assert int(rec["actions"][ri]) == r["action"]
+
+
+def test_config4_resnet_15x15_arena_bit_exact_vs_oracle():
+    """configs[4]'s head-to-head arena (evaluator.py:50-104) on the 15x15 ResidualBlock net: 4 games at 200 simulations
+    (NUM_EVAL_SIMULATIONS, constants.py) between two weight sets, engine vs the oracle's free-running games."""
+    from concurrent.futures import ThreadPoolExecutor
+    n, k, S, G, seed0 = 15, 5, 200, 4, 8800
+    a, b = synthetic_resnet_state_dict(n, 1), synthetic_resnet_state_dict(n, 2)
+    e = az.Engine(n, k, S, G, model="resnet", log_table=orc.numpy_log_table(S))
+    e.load_weights(a, 0); e.load_weights(b, 1)
+    r = e.arena(G, seed0=seed0, temperature_table=orc.arena_T_table(n * n))
+    e.close()
+    o = orc.Oracle(n, k, S)
+    oa = orc.Net(n, resnet_tensors=fold_resnet_state_dict(a))
+    ob = orc.Net(n, resnet_tensors=fold_resnet_state_dict(b))
+
+    def one(g):
+        return o.arena_game(oa, ob, g, np.random.RandomState(seed0 + g).random_sample(n * n))
+
+    with ThreadPoolExecutor(min(G, _host_threads())) as ex:
+        outs = list(ex.map(one, range(G)))
+    w = l = d = 0
+    for g, ro in enumerate(outs):
+        assert int(r["nply"][g]) == ro["nply"] and int(r["results"][g]) == ro["result"], f"arena game {g}"
+        assert np.array_equal(r["actions"][g][:ro["nply"]], ro["actions"])
+        w += ro["result"] == 1; l += ro["result"] == 2; d += ro["result"] == 3
+    assert (r["wins"], r["losses"], r["draws"]) == (w, l, d) and r["total"] == G
