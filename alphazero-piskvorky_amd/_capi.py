@@ -27,7 +27,7 @@ AZ_MODEL_PLAIN, AZ_MODEL_RESNET = 0, 1
 EXPORTS = [
     "az_create", "az_destroy", "az_last_error", "az_load_weights", "az_load_weights_resnet", "az_net_eval", "az_search", "az_selfplay",
     "az_selfplay_begin", "az_selfplay_step", "az_selfplay_end", "az_selfplay_games", "az_selfplay_records", "az_record_bytes", "az_selfplay_pack", "az_examples_from_packed",
-    "az_examples_gather", "az_arena", "az_rules_replay", "az_rng_selfplay_tape", "az_rng_uniforms", "az_set_profiling", "az_set_subtree_reuse", "az_get_counters",
+    "az_examples_gather", "az_arena", "az_rules_replay", "az_rng_selfplay_tape", "az_rng_uniforms", "az_set_profiling", "az_set_subtree_reuse", "az_get_counters", "az_get_lanes",
 ]
 
 
@@ -39,7 +39,7 @@ class az_config(C.Structure):
     _fields_ = [("board_size", C.c_int32), ("win_length", C.c_int32), ("num_simulations", C.c_int32),
                 ("slots", C.c_int32), ("c_puct", C.c_double), ("dirichlet_alpha", C.c_double),
                 ("dirichlet_weight", C.c_double), ("eval_kind", C.c_int32), ("device", C.c_int32),
-                ("log_table", C.POINTER(C.c_float)), ("model", C.c_int32)]
+                ("log_table", C.POINTER(C.c_float)), ("model", C.c_int32), ("engines", C.c_int32)]
 
 
 class az_selfplay_args(C.Structure):
@@ -140,10 +140,11 @@ def rng_uniforms(seed, count):
 
 
 class Engine:
-    """One engine per GPU (az_create .. az_destroy)."""
+    """One engine per GPU (az_create .. az_destroy).  engines = lanes inside the engine (az_config.engines): the slots
+    are split over that many HIP streams driven by the library's own host threads; 0 lets the library choose."""
 
     def __init__(self, board_size, win_length, num_simulations, slots, c_puct=2.0, dirichlet_alpha=0.3,
-                 dirichlet_weight=0.25, synthetic=False, device=0, log_table=None, model="plain"):
+                 dirichlet_weight=0.25, synthetic=False, device=0, log_table=None, model="plain", engines=0):
         self.n, self.k, self.S, self.slots = board_size, win_length, num_simulations, slots
         self.device = int(device)
         if model not in ("plain", "resnet"):
@@ -156,7 +157,7 @@ class Engine:
         cfg = az_config(board_size, win_length, num_simulations, slots, c_puct, dirichlet_alpha, dirichlet_weight,
                         AZ_EVAL_SYNTHETIC if synthetic else AZ_EVAL_NET, device,
                         None if self._log_table is None else self._log_table.ctypes.data_as(C.POINTER(C.c_float)),
-                        AZ_MODEL_RESNET if model == "resnet" else AZ_MODEL_PLAIN)
+                        AZ_MODEL_RESNET if model == "resnet" else AZ_MODEL_PLAIN, int(engines))
         self.h = C.c_void_p()
         rc = lib().az_create(C.byref(cfg), C.byref(self.h))
         if rc:
@@ -326,96 +327,19 @@ class Engine:
     def set_profiling(self, on):
         lib().az_set_profiling(self.h, 1 if on else 0)
 
+    def lanes(self):
+        """Number of lanes (streams + driver threads) inside the engine, az_config.engines after the library's choice."""
+        return int(lib().az_get_lanes(self.h))
+
     def counters(self):
         c = az_counters()
         lib().az_get_counters(self.h, C.byref(c))
         return c.as_dict()
 
 
-class MultiEngine:
-    """K engines on one GPU, each with slots/K game slots and its own HIP stream, driven from K host threads.
-    Games are identified by id and seeded per id, so the episode is the same as with one engine; what changes is
-    that one engine's latency-bound tree/FC kernels run underneath another engine's conv trunk."""
+class MultiEngine(Engine):
+    """An engine with an explicit number of lanes (kept for callers written against the host-thread version: the
+    lanes, their streams and their driver threads now live inside the library, az_config.engines)."""
 
     def __init__(self, board_size, win_length, num_simulations, slots, engines=1, **kw):
-        from concurrent.futures import ThreadPoolExecutor
-        self.K = max(1, min(int(engines), slots))
-        per = (slots + self.K - 1) // self.K
-        self.parts = [Engine(board_size, win_length, num_simulations, min(per, slots - i * per), **kw) for i in range(self.K)]
-        self.n, self.nn, self.record_bytes = self.parts[0].n, self.parts[0].nn, self.parts[0].record_bytes
-        self.pool = ThreadPoolExecutor(self.K)
-        self.last_records = 0
-
-    def _all(self, fn):
-        return list(self.pool.map(fn, range(self.K)))
-
-    def load_weights(self, sd, slot=0):
-        for p in self.parts:
-            p.load_weights(sd, slot)
-
-    def set_subtree_reuse(self, on):
-        for p in self.parts:
-            p.set_subtree_reuse(on)
-
-    def selfplay_begin(self, num_games, seed0=0, max_plies=0, temperature_table=None):
-        per = (num_games + self.K - 1) // self.K
-        self.shares = [max(0, min(per, num_games - i * per)) for i in range(self.K)]
-        self._all(lambda i: self.parts[i].selfplay_begin(self.shares[i], seed0 + i * per, max_plies, temperature_table)
-                  if self.shares[i] else None)
-
-    @staticmethod
-    def _sum(cs):
-        out = dict(cs[0])
-        for c in cs[1:]:
-            for k, v in c.items():
-                out[k] = max(out[k], v) if k == "seconds" else out[k] + v
-        return out
-
-    def selfplay_step(self, max_steps=1):
-        res = self._all(lambda i: self.parts[i].selfplay_step(max_steps) if self.shares[i] else (0, None))
-        cs = [c for _, c in res if c is not None]
-        return sum(a for a, _ in res), self._sum(cs)
-
-    def selfplay_end(self):
-        cs = self._all(lambda i: self.parts[i].selfplay_end() if self.shares[i] else None)
-        cs = [c for c in cs if c is not None]
-        self.last_records = sum(int(c["records"]) for c in cs)
-        return self._sum(cs)
-
-    def selfplay(self, num_games, seed0=0, max_plies=0, temperature_table=None, **kw):
-        self.selfplay_begin(num_games, seed0, max_plies, temperature_table)
-        active = 1
-        while active > 0:
-            active, _ = self.selfplay_step(1 << 20)
-        return self.selfplay_end()
-
-    def step_one_engine(self, index=0, max_steps=1, profile=False):
-        """Plays plies on ONE part while the others are idle (exclusive kernel timing for the roofline)."""
-        self.parts[index].set_profiling(profile)
-        try:
-            return self.parts[index].selfplay_step(max_steps)
-        finally:
-            self.parts[index].set_profiling(False)
-
-    def games(self):
-        outs = [p.games() for i, p in enumerate(self.parts) if self.shares[i]]
-        return np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs])
-
-    def records(self):
-        outs = [p.records() for i, p in enumerate(self.parts) if self.shares[i]]
-        return {k: np.concatenate([o[k] for o in outs]) for k in outs[0]}
-
-    def examples_from_packed(self, *a):
-        return self.parts[0].examples_from_packed(*a)
-
-    def pack_into(self, dev_ptr):
-        off = 0
-        for i, p in enumerate(self.parts):
-            if self.shares[i] and p.last_records:
-                p.pack_into(dev_ptr + off)
-                off += p.last_records * self.record_bytes
-
-    def close(self):
-        for p in self.parts:
-            p.close()
-        self.pool.shutdown(wait=False)
+        super().__init__(board_size, win_length, num_simulations, slots, engines=max(1, min(int(engines), slots)), **kw)

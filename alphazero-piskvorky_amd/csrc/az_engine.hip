@@ -37,49 +37,62 @@ struct PackedNet {
     ResWeights rw{};
 };
 
-struct az_engine {
-    az_config cfg{};
-    int n = 0, nn = 0, RW = 0, R = 0, PATH = 0, num_cus = 256;
-    std::string err;
+// One lane = one HIP stream with its own game slots and search state.  The lanes of an engine share the weights, the
+// episode's record/tape buffers and ONE queue of game ids (a device counter every lane's refill claims from), and are
+// driven by one host thread each: a lane's latency-bound tree / FC kernels run underneath another lane's conv trunk.
+struct Lane {
+    int index = 0;
     hipStream_t stream = nullptr;
-    const SizeOps *ops = nullptr;
     DevState d{};
-    // per-engine buffers
     DevBuf board, s_game, s_ply, s_player, s_last, s_status, s_net, edges, rows_used, path, depth, leaf_kind, leaf,
-        leaf_last, logits, vhid, pol_feat, T_table, log_table, sqrt_table, noise_off, cnt, next_game, active, carried;
-    // per-episode buffers
-    DevBuf dbg, scratch;
-    int split_max = 32;            // use the split (low-latency) trunk when at most this many slots are active (measured crossover)
-    DevBuf noise, u, rec_planes, rec_last, rec_action, rec_mover, rec_pi, rec_visits, g_nply, g_result, src_index;
-    int episode_games = 0;
-    int64_t tape_len = 0;          // doubles per game in the noise tape
-    bool have_episode = false;
-    std::vector<int> h_nply, h_result;
-    PackedNet net[2];
-    az_counters last{};
-    // running episode (az_selfplay_begin .. az_selfplay_end)
-    struct Run {
-        bool open = false;
-        int num_games = 0, max_plies = 0, active = 0;
-        bool add_noise = true, arena = false, preset = false, profile = true;
-        az_counters c{};
-        double trunk_ms = 0.0, nn_ms = 0.0, step_ms = 0.0;
-        int64_t reused_roots = 0;
-    } run;
-    // profiling events
-    std::vector<hipEvent_t> ev;
-    bool profile = false;          // HIP events around every trunk / FC launch (az_set_profiling)
+        leaf_last, logits, vhid, pol_feat, cnt, active_dev, carried, dbg, scratch;
     // one ply (k_begin, (S+1) x {trunk, fc, step}, k_move) captured once as a hipGraph and replayed every ply:
     // 3(S+1)+2 launches (6(S+1)+2 with the split trunk) become one submission.  Indexed [split trunk][arena].
     struct PlyGraph {
         hipGraphExec_t exec = nullptr;
         LaunchCtx key{};           // kernel arguments baked into the nodes; any change re-captures
     } graph[2][2];
+    std::vector<hipEvent_t> ev;    // profiling events
+    // progress of the open episode
+    int active = 0;                // active slots after the last refill
+    int plies_played = 0;          // plies this lane has played in the open episode
+    int64_t steps = 0, trunk_launches = 0, plies = 0;
+    double trunk_ms = 0.0, nn_ms = 0.0, step_ms = 0.0;
+    int rc = AZ_OK;                // result of the last threaded call on this lane
+    std::string err;
+};
+
+struct az_engine {
+    az_config cfg{};
+    int n = 0, nn = 0, RW = 0, R = 0, PATH = 0, num_cus = 256;
+    std::string err;
+    hipStream_t stream = nullptr;  // lane 0's stream: uploads and copies of the shared buffers
+    const SizeOps *ops = nullptr;
+    std::vector<Lane> lanes;
+    // shared by the lanes: tables, the game-id queue, the episode's tapes and records
+    DevBuf T_table, log_table, sqrt_table, noise_off, next_game;
+    DevBuf noise, u, rec_planes, rec_last, rec_action, rec_mover, rec_pi, rec_visits, g_nply, g_result, src_index;
+    int split_max = 32;            // use the split (low-latency) trunk when at most this many slots of a lane are active (measured crossover)
+    int episode_games = 0;
+    int64_t tape_len = 0;          // doubles per game in the noise tape
+    bool have_episode = false;
+    int reuse = 0;
+    std::vector<int> h_nply, h_result;
+    PackedNet net[2];
+    az_counters last{};
+    // running episode (az_selfplay_begin .. az_selfplay_end)
+    struct Run {
+        bool open = false;
+        int num_games = 0, max_plies = 0;
+        bool add_noise = true, arena = false, preset = false, profile = true;
+        az_counters c{};
+        int64_t reused_roots = 0;
+    } run;
+    bool profile = false;          // HIP events around every trunk / FC launch (az_set_profiling); lanes then play one after another
     bool use_graph = true;         // AZ_GRAPH=0: launch kernel by kernel
     TapeProducer *tapes = nullptr; // running while a self-play episode with engine-generated tapes is open
     bool stream_tapes = true;      // AZ_TAPE_STREAM=0: generate every tape before the first ply
-    int tape_threads = 4;          // AZ_TAPE_THREADS: host threads of this engine's tape producer
-    int plies_played = 0;          // lock-step plies of the open episode
+    int tape_threads = 4;          // AZ_TAPE_THREADS: host threads of the tape producer
 };
 
 static void stop_tapes(az_engine *e)
@@ -87,17 +100,17 @@ static void stop_tapes(az_engine *e)
     if (e->tapes) { e->tapes->shutdown(); delete e->tapes; e->tapes = nullptr; }
 }
 
-static LaunchCtx ctx_of_impl(const az_engine *e)
+static LaunchCtx ctx_of_impl(const az_engine *e, const Lane &L)
 {
     LaunchCtx c{};
-    c.stream = e->stream;
-    c.d = e->d;
+    c.stream = L.stream;
+    c.d = L.d;
     for (int i = 0; i < 2; i++) { c.w[i] = e->net[i].w; c.rw[i] = e->net[i].rw; }
     c.model = e->cfg.model;
     c.synthetic = e->cfg.eval_kind == AZ_EVAL_SYNTHETIC;
-    c.feat = (float *)e->pol_feat.p;
-    c.dbg = (unsigned long long *)e->dbg.p;
-    c.scratch = (float *)e->scratch.p;
+    c.feat = (float *)L.pol_feat.p;
+    c.dbg = (unsigned long long *)L.dbg.p;
+    c.scratch = (float *)L.scratch.p;
     return c;
 }
 
@@ -364,6 +377,22 @@ static int setup_tables(az_engine *e)
     return AZ_OK;
 }
 
+// lanes of an engine when the caller leaves it to the library: small boards are launch-bound (one lane); otherwise one
+// lane per 128 slots up to four (measured at 15x15 / 1024 slots: 1/2/3/4/6/8 lanes -> 2.38/2.47/2.53/2.58/1.95/2.11 M exp/s)
+static int auto_lanes(int n, int slots)
+{
+    if (n <= 5) return 1;
+    const int k = slots / 128;
+    return k < 1 ? 1 : (k > 4 ? 4 : k);
+}
+
+// every lane's DevState carries the shared pointers and scalars
+template <class F>
+static void each_state(az_engine *e, F f)
+{
+    for (Lane &L : e->lanes) f(L.d);
+}
+
 extern "C" int az_create(const az_config *cfg, az_engine **out)
 {
     if (!cfg || !out) return fail(nullptr, AZ_ERR_INVALID, "null argument");
@@ -374,6 +403,7 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
     if (cfg->num_simulations < 1 || cfg->num_simulations > 1024) return fail(nullptr, AZ_ERR_INVALID, "num_simulations must be 1..1024");
     if (cfg->slots < 1 || cfg->slots > 65536) return fail(nullptr, AZ_ERR_INVALID, "slots must be 1..65536");
     if (cfg->model != AZ_MODEL_PLAIN && cfg->model != AZ_MODEL_RESNET) return fail(nullptr, AZ_ERR_INVALID, "unknown model kind %d", cfg->model);
+    if (cfg->engines < 0 || cfg->engines > 16) return fail(nullptr, AZ_ERR_INVALID, "engines must be 0 (auto) .. 16");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, AZ_ERR_NO_DEVICE, "no HIP device: this engine has no CPU fallback");
@@ -390,72 +420,86 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
         delete e;
         return fail(nullptr, AZ_ERR_INVALID, "board size %d is not built into this library", cfg->board_size);
     }
+    int K = cfg->engines > 0 ? cfg->engines : auto_lanes(e->n, cfg->slots);
+    if (K > cfg->slots) K = cfg->slots;
+    const int per = (cfg->slots + K - 1) / K;
+    K = (cfg->slots + per - 1) / per;              // no empty lane
+    e->cfg.engines = K;
+    e->lanes.resize(K);
     DeviceGuard guard(cfg->device);          // the caller's current device is restored on return
     hipError_t hr = guard.rc;
-    // Own hardware queue per engine: the runtime multiplexes the streams of one priority level over a small pool of
-    // hardware queues, so next to a framework that has already created streams (PyTorch's context) two engines can
+    // Own hardware queue per lane: the runtime multiplexes the streams of one priority level over a small pool of
+    // hardware queues, so next to a framework that has already created streams (PyTorch's context) two lanes can
     // land on one queue and stop overlapping (measured: episode 11.6 -> 15.3 s).  High-priority streams draw from
     // their own pool.  AZ_STREAM_PRIORITY=0 keeps the default priority.
-    if (hr == hipSuccess) hr = g_streams.acquire(cfg->device, true, &e->stream);
+    for (int i = 0; i < K && hr == hipSuccess; i++) {
+        e->lanes[i].index = i;
+        hr = g_streams.acquire(cfg->device, true, &e->lanes[i].stream);
+    }
     if (hr != hipSuccess) {
         int rc = fail(nullptr, AZ_ERR_HIP, "device init failed: %s", hipGetErrorString(hr));
-        delete e;
+        az_destroy(e);
         return rc;
     }
-    const size_t B = (size_t)cfg->slots;
+    e->stream = e->lanes[0].stream;
+    if (cfg->model == AZ_MODEL_PLAIN) {
+        const char *sm = getenv("AZ_SPLIT_MAX");      // 0 disables the split trunk, a large value forces it
+        if (sm) e->split_max = atoi(sm);
+    } else {
+        e->split_max = 0;
+    }
     int rc = AZ_OK;
-#define ALLOC(buf, bytes) if (!rc) rc = dev_alloc(e, e->buf, (bytes))
-    ALLOC(board, B * 8 * sizeof(u64));
-    ALLOC(s_game, B * 4); ALLOC(s_ply, B * 4); ALLOC(s_player, B * 4); ALLOC(s_last, B * 4);
-    ALLOC(s_status, B * 4); ALLOC(s_net, B * 4);
-    ALLOC(edges, B * (size_t)e->R * e->RW * sizeof(Edge));
-    ALLOC(rows_used, B * 4); ALLOC(depth, B * 4);
-    ALLOC(path, (B * (size_t)e->PATH + 64) * 4);   // +64: k_step's speculative path[lane] read of the last slot
-    ALLOC(leaf_kind, B * 4); ALLOC(leaf, B * 8 * sizeof(u64)); ALLOC(leaf_last, B * 4);
-    ALLOC(logits, B * (size_t)e->RW * 4); ALLOC(vhid, B * 64 * 4);
-    ALLOC(pol_feat, B * (size_t)((((cfg->model == AZ_MODEL_RESNET ? 3 : 6) * e->nn + 3) / 4) * 4) * 4);   // feature rows [B][FROW], zero tail stays zero
-    ALLOC(cnt, B * CNT_STRIDE * sizeof(unsigned long long)); ALLOC(next_game, 16); ALLOC(active, 16);
-    ALLOC(carried, B * 4);
-    ALLOC(T_table, (size_t)(e->nn + 4) * sizeof(double));
+    for (int i = 0; i < K && !rc; i++) {
+        Lane &L = e->lanes[i];
+        const size_t B = (size_t)std::min(per, cfg->slots - i * per);
+#define ALLOC(buf, bytes) if (!rc) rc = dev_alloc(e, L.buf, (bytes))
+        ALLOC(board, B * 8 * sizeof(u64));
+        ALLOC(s_game, B * 4); ALLOC(s_ply, B * 4); ALLOC(s_player, B * 4); ALLOC(s_last, B * 4);
+        ALLOC(s_status, B * 4); ALLOC(s_net, B * 4);
+        ALLOC(edges, B * (size_t)e->R * e->RW * sizeof(Edge));
+        ALLOC(rows_used, B * 4); ALLOC(depth, B * 4);
+        ALLOC(path, (B * (size_t)e->PATH + 64) * 4);   // +64: k_step's speculative path[lane] read of the last slot
+        ALLOC(leaf_kind, B * 4); ALLOC(leaf, B * 8 * sizeof(u64)); ALLOC(leaf_last, B * 4);
+        ALLOC(logits, B * (size_t)e->RW * 4); ALLOC(vhid, B * 64 * 4);
+        ALLOC(pol_feat, B * (size_t)((((cfg->model == AZ_MODEL_RESNET ? 3 : 6) * e->nn + 3) / 4) * 4) * 4);   // feature rows [B][FROW], zero tail stays zero
+        ALLOC(cnt, B * CNT_STRIDE * sizeof(unsigned long long)); ALLOC(active_dev, 16);
+        ALLOC(carried, B * 4);
 #ifdef AZ_STAMPS
-    ALLOC(dbg, (B * 16 + 4096 * 32) * sizeof(unsigned long long));
+        ALLOC(dbg, (B * 16 + 4096 * 32) * sizeof(unsigned long long));
 #endif
+        if (e->split_max > 0)    // zeroed once: the padding ring of the packed images is never written afterwards
+            ALLOC(scratch, (size_t)e->ops->split_scratch_floats((int)B) * sizeof(float));
 #undef ALLOC
+        DevState &d = L.d;
+        d.B = (int)B; d.R = e->R; d.S = cfg->num_simulations; d.k = cfg->win_length;
+        d.c_puct = cfg->c_puct; d.w_noise = cfg->dirichlet_weight;
+        d.one_minus_w = (float)(1.0 - cfg->dirichlet_weight);   // Python float (1 - w) as a weak scalar -> float32 (Q8)
+        d.board = (u64 *)L.board.p;
+        d.s_game = (int *)L.s_game.p; d.s_ply = (int *)L.s_ply.p; d.s_player = (int *)L.s_player.p;
+        d.s_last = (int *)L.s_last.p; d.s_status = (int *)L.s_status.p; d.s_net = (int *)L.s_net.p;
+        d.edges = (Edge *)L.edges.p; d.rows_used = (int *)L.rows_used.p; d.path = (unsigned *)L.path.p;
+        d.depth = (int *)L.depth.p; d.leaf_kind = (int *)L.leaf_kind.p; d.leaf = (u64 *)L.leaf.p;
+        d.leaf_last = (int *)L.leaf_last.p; d.logits = (float *)L.logits.p; d.vhid = (float *)L.vhid.p;
+        d.cnt = (unsigned long long *)L.cnt.p; d.active = (int *)L.active_dev.p;
+        d.carried = (int *)L.carried.p; d.reuse = 0;
+        d.v2w[0] = d.v2w[1] = d.v2b[0] = d.v2b[1] = nullptr;
+    }
+    if (!rc) rc = dev_alloc(e, e->next_game, 16);
+    if (!rc) rc = dev_alloc(e, e->T_table, (size_t)(e->nn + 4) * sizeof(double));
     if (!rc) rc = setup_tables(e);
     if (rc) {
         g_create_error = e->err;
         az_destroy(e);
         return rc;
     }
-    DevState &d = e->d;
-    d.B = cfg->slots; d.R = e->R; d.S = cfg->num_simulations; d.k = cfg->win_length;
-    d.c_puct = cfg->c_puct; d.w_noise = cfg->dirichlet_weight;
-    d.one_minus_w = (float)(1.0 - cfg->dirichlet_weight);   // Python float (1 - w) as a weak scalar -> float32 (Q8)
-    d.board = (u64 *)e->board.p;
-    d.s_game = (int *)e->s_game.p; d.s_ply = (int *)e->s_ply.p; d.s_player = (int *)e->s_player.p;
-    d.s_last = (int *)e->s_last.p; d.s_status = (int *)e->s_status.p; d.s_net = (int *)e->s_net.p;
-    d.edges = (Edge *)e->edges.p; d.rows_used = (int *)e->rows_used.p; d.path = (unsigned *)e->path.p;
-    d.depth = (int *)e->depth.p; d.leaf_kind = (int *)e->leaf_kind.p; d.leaf = (u64 *)e->leaf.p;
-    d.leaf_last = (int *)e->leaf_last.p; d.logits = (float *)e->logits.p; d.vhid = (float *)e->vhid.p;
-    d.T_table = (const double *)e->T_table.p; d.log_table = (const float *)e->log_table.p;
-    d.sqrt_table = (const double *)e->sqrt_table.p; d.noise_off = (const int *)e->noise_off.p;
-    d.cnt = (unsigned long long *)e->cnt.p; d.next_game = (int *)e->next_game.p; d.active = (int *)e->active.p;
-    d.carried = (int *)e->carried.p; d.reuse = 0;
+    each_state(e, [&](DevState &d) {
+        d.T_table = (const double *)e->T_table.p; d.log_table = (const float *)e->log_table.p;
+        d.sqrt_table = (const double *)e->sqrt_table.p; d.noise_off = (const int *)e->noise_off.p;
+        d.next_game = (int *)e->next_game.p;
+    });
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
-    }
-    d.v2w[0] = d.v2w[1] = d.v2b[0] = d.v2b[1] = nullptr;
-    if (cfg->model == AZ_MODEL_PLAIN) {
-        const char *sm = getenv("AZ_SPLIT_MAX");      // 0 disables the split trunk, a large value forces it
-        if (sm) e->split_max = atoi(sm);
-        if (e->split_max > 0) {
-            // zeroed once: the padding ring of the packed images is never written afterwards
-            int rc2 = dev_alloc(e, e->scratch, (size_t)e->ops->split_scratch_floats(cfg->slots) * sizeof(float), true);
-            if (rc2) { g_create_error = e->err; az_destroy(e); return rc2; }
-        }
-    } else {
-        e->split_max = 0;
     }
     const char *pe = getenv("AZ_PROFILE_EVENTS");
     e->profile = pe && pe[0] == '1';
@@ -465,14 +509,13 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
     e->stream_tapes = !(ts && ts[0] == '0');
     {
         // default: the host threads of this rank (hardware threads / ranks on the node, torchrun's LOCAL_WORLD_SIZE)
-        // shared by the four engines of a GPU
         const unsigned hc = std::thread::hardware_concurrency();
         const char *lw = getenv("LOCAL_WORLD_SIZE");
         const int ranks = lw && atoi(lw) > 0 ? atoi(lw) : 1;
-        int t = hc ? (int)hc / (4 * ranks) : 2;
+        int t = hc ? (int)hc / (4 * ranks) * K : 2 * K;
         const char *tt = getenv("AZ_TAPE_THREADS");
         if (tt) t = atoi(tt);
-        e->tape_threads = t < 1 ? 1 : (t > 16 ? 16 : t);
+        e->tape_threads = t < 1 ? 1 : (t > 32 ? 32 : t);
     }
     if (hipStreamSynchronize(e->stream) != hipSuccess) {
         g_create_error = "stream sync failed in az_create";
@@ -488,23 +531,29 @@ extern "C" void az_destroy(az_engine *e)
     if (!e) return;
     DeviceGuard guard(e->cfg.device);
     stop_tapes(e);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
-    DevBuf *all[] = {&e->board, &e->s_game, &e->s_ply, &e->s_player, &e->s_last, &e->s_status, &e->s_net, &e->edges,
-                     &e->rows_used, &e->path, &e->depth, &e->leaf_kind, &e->leaf, &e->leaf_last, &e->logits, &e->vhid,
-                     &e->pol_feat, &e->T_table, &e->log_table, &e->sqrt_table, &e->noise_off, &e->cnt,
-                     &e->next_game, &e->active, &e->carried, &e->scratch, &e->noise, &e->u, &e->rec_planes, &e->rec_last, &e->rec_action,
-                     &e->rec_mover, &e->rec_pi, &e->rec_visits, &e->g_nply, &e->g_result, &e->src_index};
-    for (DevBuf *b : all) dev_free(*b);
+    for (Lane &L : e->lanes)
+        if (L.stream) (void)hipStreamSynchronize(L.stream);
+    for (Lane &L : e->lanes) {
+        DevBuf *all[] = {&L.board, &L.s_game, &L.s_ply, &L.s_player, &L.s_last, &L.s_status, &L.s_net, &L.edges, &L.rows_used,
+                         &L.path, &L.depth, &L.leaf_kind, &L.leaf, &L.leaf_last, &L.logits, &L.vhid, &L.pol_feat, &L.cnt,
+                         &L.active_dev, &L.carried, &L.dbg, &L.scratch};
+        for (DevBuf *b : all) dev_free(*b);
+        for (hipEvent_t ev : L.ev) (void)hipEventDestroy(ev);
+        for (int i = 0; i < 4; i++)
+            if (L.graph[i >> 1][i & 1].exec) (void)hipGraphExecDestroy(L.graph[i >> 1][i & 1].exec);
+    }
+    DevBuf *shared[] = {&e->T_table, &e->log_table, &e->sqrt_table, &e->noise_off, &e->next_game, &e->noise, &e->u,
+                        &e->rec_planes, &e->rec_last, &e->rec_action, &e->rec_mover, &e->rec_pi, &e->rec_visits, &e->g_nply,
+                        &e->g_result, &e->src_index};
+    for (DevBuf *b : shared) dev_free(*b);
     for (int s = 0; s < 2; s++) {
         PackedNet &p = e->net[s];
         DevBuf *nb[] = {&p.c1, &p.c2, &p.c3, &p.hd, &p.pf, &p.vf, &p.c1b, &p.c2b, &p.c3b, &p.hdb, &p.pfb, &p.vfb, &p.v2w, &p.v2b};
         for (DevBuf *b : nb) dev_free(*b);
         for (int i = 0; i < 6; i++) { dev_free(p.rblk[i]); dev_free(p.rblkb[i]); }
     }
-    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
-    for (int i = 0; i < 4; i++)
-        if (e->graph[i >> 1][i & 1].exec) (void)hipGraphExecDestroy(e->graph[i >> 1][i & 1].exec);
-    g_streams.release(e->cfg.device, true, e->stream);
+    for (Lane &L : e->lanes)
+        if (L.stream) g_streams.release(e->cfg.device, true, L.stream);
     delete e;
 }
 
@@ -534,8 +583,7 @@ extern "C" int az_load_weights(az_engine *e, int slot, const float *const *t)
     p.w.hd = (const float *)p.hd.p; p.w.pf = (const float *)p.pf.p; p.w.vf = (const float *)p.vf.p;
     p.w.c1b = (const float *)p.c1b.p; p.w.c2b = (const float *)p.c2b.p; p.w.c3b = (const float *)p.c3b.p;
     p.w.hdb = (const float *)p.hdb.p; p.w.pfb = (const float *)p.pfb.p; p.w.vfb = (const float *)p.vfb.p;
-    e->d.v2w[slot] = (const float *)p.v2w.p;
-    e->d.v2b[slot] = (const float *)p.v2b.p;
+    each_state(e, [&](DevState &d) { d.v2w[slot] = (const float *)p.v2w.p; d.v2b[slot] = (const float *)p.v2b.p; });
     p.loaded = true;
     return AZ_OK;
 }
@@ -567,8 +615,7 @@ extern "C" int az_load_weights_resnet(az_engine *e, int slot, const float *const
     p.w = NetWeights{};
     p.w.pf = (const float *)p.pf.p; p.w.vf = (const float *)p.vf.p;
     p.w.pfb = (const float *)p.pfb.p; p.w.vfb = (const float *)p.vfb.p;
-    e->d.v2w[slot] = (const float *)p.v2w.p;
-    e->d.v2b[slot] = (const float *)p.v2b.p;
+    each_state(e, [&](DevState &d) { d.v2w[slot] = (const float *)p.v2w.p; d.v2b[slot] = (const float *)p.v2b.p; });
     p.loaded = true;
     return AZ_OK;
 }
@@ -590,18 +637,19 @@ static int ensure_episode_buffers(az_engine *e, int games, bool need_noise)
     if (need_noise) ALLOC(noise, G * (size_t)e->tape_len * sizeof(double), false);
 #undef ALLOC
     if (rc) return rc;
-    DevState &d = e->d;
-    d.rec_planes = (u64 *)e->rec_planes.p; d.rec_last = (short *)e->rec_last.p; d.rec_action = (short *)e->rec_action.p;
-    d.rec_mover = (unsigned char *)e->rec_mover.p; d.rec_pi = (float *)e->rec_pi.p;
-    d.rec_visits = (unsigned short *)e->rec_visits.p; d.g_nply = (int *)e->g_nply.p; d.g_result = (int *)e->g_result.p;
-    d.u = (const double *)e->u.p; d.noise = (const double *)e->noise.p; d.noise_stride = e->tape_len;
+    each_state(e, [&](DevState &d) {
+        d.rec_planes = (u64 *)e->rec_planes.p; d.rec_last = (short *)e->rec_last.p; d.rec_action = (short *)e->rec_action.p;
+        d.rec_mover = (unsigned char *)e->rec_mover.p; d.rec_pi = (float *)e->rec_pi.p;
+        d.rec_visits = (unsigned short *)e->rec_visits.p; d.g_nply = (int *)e->g_nply.p; d.g_result = (int *)e->g_result.p;
+        d.u = (const double *)e->u.p; d.noise = (const double *)e->noise.p; d.noise_stride = e->tape_len;
+    });
     return AZ_OK;
 }
 
 struct EpisodeSpec {
     int num_games = 0, max_plies = 0;
     bool add_noise = true, arena = false;
-    bool preset = false;      // slot 0 already holds a position (az_search); skip the initial refill
+    bool preset = false;      // slot 0 of lane 0 already holds a position (az_search); skip the initial refill
     bool profile = true;      // this episode may be timed with HIP events (only when az_set_profiling is on)
 };
 
@@ -614,30 +662,59 @@ static int host_threads()
     return t < 1 ? 1 : (t > 64 ? 64 : t);
 }
 
+// errors inside a lane's host thread are kept on the lane and reported by the joining caller
+static int lane_fail(Lane &L, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    L.err = buf;
+    L.rc = code;
+    return code;
+}
+#define HIPCHECK_L(L, call)                                                                        \
+    do {                                                                                           \
+        hipError_t _r = (call);                                                                    \
+        if (_r != hipSuccess)                                                                      \
+            return lane_fail(L, AZ_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+
 static int episode_begin(az_engine *e, const EpisodeSpec &sp)
 {
-    DevState &d = e->d;
     const bool net = e->cfg.eval_kind == AZ_EVAL_NET;
     if (net && !e->net[0].loaded) return fail(e, AZ_ERR_NO_WEIGHTS, "weights slot 0 not loaded");
     if (net && sp.arena && !e->net[1].loaded) return fail(e, AZ_ERR_NO_WEIGHTS, "weights slot 1 (baseline) not loaded");
-    d.max_plies = sp.max_plies; d.add_noise = sp.add_noise ? 1 : 0; d.arena = sp.arena ? 1 : 0;
-    d.total_games = sp.num_games;
-    HIPCHECK(e, hipMemsetAsync(e->cnt.p, 0, e->cnt.bytes, e->stream));
-    HIPCHECK(e, hipMemsetAsync(e->carried.p, 0xFF, e->carried.bytes, e->stream));      // -1: every slot starts from a fresh root
+    each_state(e, [&](DevState &d) {
+        d.max_plies = sp.max_plies; d.add_noise = sp.add_noise ? 1 : 0; d.arena = sp.arena ? 1 : 0;
+        d.total_games = sp.num_games; d.reuse = e->reuse;
+    });
     az_engine::Run &r = e->run;
     r = az_engine::Run();
-    e->plies_played = 0;
     r.num_games = sp.num_games; r.max_plies = sp.max_plies; r.add_noise = sp.add_noise; r.arena = sp.arena;
     r.preset = sp.preset; r.profile = sp.profile;
-    if (!sp.preset) {
-        HIPCHECK(e, hipMemsetAsync(e->s_status.p, 0, e->s_status.bytes, e->stream));
-        HIPCHECK(e, hipMemsetAsync(e->next_game.p, 0, 16, e->stream));
-        hipLaunchKernelGGL(k_refill, dim3(1), dim3(1024), 0, e->stream, d);
-        HIPCHECK(e, hipMemcpyAsync(&r.active, e->active.p, 4, hipMemcpyDeviceToHost, e->stream));
-        HIPCHECK(e, hipStreamSynchronize(e->stream));
-    } else {
-        r.active = 1;
+    HIPCHECK(e, hipMemsetAsync(e->next_game.p, 0, 16, e->stream));
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    // the first refill hands every lane an equal share of the games (as many as its slots hold); afterwards a freed
+    // slot of ANY lane takes the next id of the shared queue, so no lane idles while another still has games waiting
+    const int K = (int)e->lanes.size();
+    const int share = (sp.num_games + K - 1) / K;
+    for (Lane &L : e->lanes) {
+        L.active = 0; L.plies_played = 0; L.steps = L.trunk_launches = L.plies = 0;
+        L.trunk_ms = L.nn_ms = L.step_ms = 0.0; L.rc = AZ_OK; L.err.clear();
+        HIPCHECK(e, hipMemsetAsync(L.cnt.p, 0, L.cnt.bytes, L.stream));
+        HIPCHECK(e, hipMemsetAsync(L.carried.p, 0xFF, L.carried.bytes, L.stream));      // -1: every slot starts from a fresh root
+        if (!sp.preset) {
+            HIPCHECK(e, hipMemsetAsync(L.s_status.p, 0, L.s_status.bytes, L.stream));
+            hipLaunchKernelGGL(k_refill, dim3(1), dim3(1024), 0, L.stream, L.d, share);
+            HIPCHECK(e, hipMemcpyAsync(&L.active, L.active_dev.p, 4, hipMemcpyDeviceToHost, L.stream));
+        } else if (L.index != 0) {
+            HIPCHECK(e, hipMemsetAsync(L.s_status.p, 0, L.s_status.bytes, L.stream));
+        }
+        HIPCHECK(e, hipStreamSynchronize(L.stream));
     }
+    if (sp.preset) e->lanes[0].active = 1;
     r.open = true;
     e->have_episode = false;
     return AZ_OK;
@@ -659,129 +736,170 @@ static void launch_ply(az_engine *e, const LaunchCtx &lc, bool use_split, int nn
     e->ops->move(lc);
 }
 
-static std::mutex g_capture_mutex;     // engines of one process capture one at a time (instantiate is not cheap, and rare)
+static std::mutex g_capture_mutex;     // lanes of one process capture one at a time (instantiate is not cheap, and rare)
 
 // returns the instantiated graph of one ply for these kernel arguments, capturing it on first use
-static int ply_graph(az_engine *e, const LaunchCtx &lc, bool use_split, int nnets, bool net, hipGraphExec_t *out)
+static int ply_graph(az_engine *e, Lane &L, const LaunchCtx &lc, bool use_split, int nnets, bool net, hipGraphExec_t *out)
 {
-    az_engine::PlyGraph &g = e->graph[use_split ? 1 : 0][nnets - 1];
+    Lane::PlyGraph &g = L.graph[use_split ? 1 : 0][nnets - 1];
     if (g.exec && memcmp(&g.key, &lc, sizeof(LaunchCtx)) == 0) { *out = g.exec; return AZ_OK; }
     std::lock_guard<std::mutex> lock(g_capture_mutex);
-    if (g.exec) { HIPCHECK(e, hipGraphExecDestroy(g.exec)); g.exec = nullptr; }
+    if (g.exec) { HIPCHECK_L(L, hipGraphExecDestroy(g.exec)); g.exec = nullptr; }
     hipGraph_t graph = nullptr;
-    HIPCHECK(e, hipStreamBeginCapture(lc.stream, hipStreamCaptureModeThreadLocal));
+    HIPCHECK_L(L, hipStreamBeginCapture(lc.stream, hipStreamCaptureModeThreadLocal));
     launch_ply(e, lc, use_split, nnets, net);
-    HIPCHECK(e, hipStreamEndCapture(lc.stream, &graph));
+    HIPCHECK_L(L, hipStreamEndCapture(lc.stream, &graph));
     hipError_t rc = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
-    if (rc != hipSuccess) { g.exec = nullptr; return fail(e, AZ_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(rc)); }
+    if (rc != hipSuccess) { g.exec = nullptr; return lane_fail(L, AZ_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(rc)); }
     memcpy(&g.key, &lc, sizeof(LaunchCtx));
     *out = g.exec;
     return AZ_OK;
 }
 
-// plays up to max_steps plies of every active slot in lock step (one "step" = MCTS.run for each active game)
-static int episode_plies(az_engine *e, int max_steps)
+// one lane plays up to max_steps plies of its active slots in lock step (one "step" = MCTS.run for each active game);
+// runs on the lane's own host thread
+static int lane_plies(az_engine *e, Lane &L, int max_steps)
 {
-    DevState &d = e->d;
-    az_engine::Run &r = e->run;
-    if (!r.open) return fail(e, AZ_ERR_STATE, "no episode is open");
+    DevState &d = L.d;
+    const az_engine::Run &r = e->run;
     const int S = d.S;
     const bool net = e->cfg.eval_kind == AZ_EVAL_NET;
     const bool prof = net && r.profile && e->profile;
     const size_t need_ev = prof ? (size_t)4 * (S + 1) : 0;
-    while (e->ev.size() < need_ev) {
+    while (L.ev.size() < need_ev) {
         hipEvent_t ev;
-        HIPCHECK(e, hipEventCreate(&ev));
-        e->ev.push_back(ev);
+        HIPCHECK_L(L, hipEventCreate(&ev));
+        L.ev.push_back(ev);
     }
     const int nnets = r.arena ? 2 : 1;
-    const LaunchCtx lc = ctx_of_impl(e);
+    const LaunchCtx lc = ctx_of_impl(e, L);
     // timing-only diagnostics (results are wrong): AZ_DIAG_SKIP=fc | step | fcstep
     const char *skip = getenv("AZ_DIAG_SKIP");
     const bool skip_fc = skip && strstr(skip, "fc"), skip_step = skip && strstr(skip, "step");
-    auto t0 = std::chrono::steady_clock::now();
-    for (int step = 0; step < max_steps && r.active > 0; step++) {
-        const bool use_split = e->split_max > 0 && e->scratch.p && r.active <= e->split_max;   // few pending boards: latency path
+    for (int step = 0; step < max_steps && L.active > 0; step++) {
+        const bool use_split = e->split_max > 0 && L.scratch.p && L.active <= e->split_max;   // few pending boards: latency path
         if (e->tapes) {       // the tapes of this ply must be on the device (streamed a wave ahead of the games)
             hipEvent_t ev = nullptr;
-            hipError_t trc = e->tapes->need(e->plies_played, &ev);
-            if (trc != hipSuccess) return fail(e, AZ_ERR_HIP, "tape producer: %s", hipGetErrorString(trc));
-            if (ev) HIPCHECK(e, hipStreamWaitEvent(e->stream, ev, 0));
+            hipError_t trc = e->tapes->need(L.plies_played, &ev);
+            if (trc != hipSuccess) return lane_fail(L, AZ_ERR_HIP, "tape producer: %s", hipGetErrorString(trc));
+            if (ev) HIPCHECK_L(L, hipStreamWaitEvent(L.stream, ev, 0));
         }
         if (e->use_graph && !prof && !skip) {
             hipGraphExec_t exec = nullptr;
-            int rcg = ply_graph(e, lc, use_split, nnets, net, &exec);
+            int rcg = ply_graph(e, L, lc, use_split, nnets, net, &exec);
             if (rcg) return rcg;
-            HIPCHECK(e, hipGraphLaunch(exec, e->stream));
-            if (net) r.c.trunk_launches += (int64_t)nnets * (S + 1);
-            r.c.steps += S + 1;
+            HIPCHECK_L(L, hipGraphLaunch(exec, L.stream));
+            if (net) L.trunk_launches += (int64_t)nnets * (S + 1);
+            L.steps += S + 1;
         } else {
-        hipLaunchKernelGGL(k_begin, dim3((d.B + 255) / 256), dim3(256), 0, e->stream, d);
-        for (int t = -1; t < S; t++) {
-            if (net) {
-                const int ei = 4 * (t + 1);
-                if (prof) HIPCHECK(e, hipEventRecord(e->ev[ei], e->stream));
-                for (int id = 0; id < nnets; id++) { if (use_split) e->ops->trunk_split(lc, id); else e->ops->trunk(lc, id); }
-                if (prof) HIPCHECK(e, hipEventRecord(e->ev[ei + 1], e->stream));
-                if (!skip_fc) for (int id = 0; id < nnets; id++) e->ops->fc(lc, id);
-                if (prof) HIPCHECK(e, hipEventRecord(e->ev[ei + 2], e->stream));
-                r.c.trunk_launches += nnets;
+            hipLaunchKernelGGL(k_begin, dim3((d.B + 255) / 256), dim3(256), 0, L.stream, d);
+            for (int t = -1; t < S; t++) {
+                if (net) {
+                    const int ei = 4 * (t + 1);
+                    if (prof) HIPCHECK_L(L, hipEventRecord(L.ev[ei], L.stream));
+                    for (int id = 0; id < nnets; id++) { if (use_split) e->ops->trunk_split(lc, id); else e->ops->trunk(lc, id); }
+                    if (prof) HIPCHECK_L(L, hipEventRecord(L.ev[ei + 1], L.stream));
+                    if (!skip_fc) for (int id = 0; id < nnets; id++) e->ops->fc(lc, id);
+                    if (prof) HIPCHECK_L(L, hipEventRecord(L.ev[ei + 2], L.stream));
+                    L.trunk_launches += nnets;
+                }
+                // t = -1 consumes the root evaluation (root N = 0 for the first selection); t >= 0 consumes simulation t
+                if (!skip_step || t < 0) e->ops->step(lc, t + 1, (t + 1 < S) ? 1 : 0);
+                if (prof) HIPCHECK_L(L, hipEventRecord(L.ev[4 * (t + 1) + 3], L.stream));
+                L.steps++;
             }
-            // t = -1 consumes the root evaluation (root N = 0 for the first selection); t >= 0 consumes simulation t
-            if (!skip_step || t < 0) e->ops->step(lc, t + 1, (t + 1 < S) ? 1 : 0);
-            if (prof) HIPCHECK(e, hipEventRecord(e->ev[4 * (t + 1) + 3], e->stream));
-            r.c.steps++;
+            e->ops->move(lc);
         }
-        e->ops->move(lc);
-        }
-        r.c.plies += r.active;
+        L.plies += L.active;
         if (r.preset) {
-            r.active = 0;
+            L.active = 0;
         } else {
-            hipLaunchKernelGGL(k_refill, dim3(1), dim3(1024), 0, e->stream, d);
-            HIPCHECK(e, hipMemcpyAsync(&r.active, e->active.p, 4, hipMemcpyDeviceToHost, e->stream));
+            hipLaunchKernelGGL(k_refill, dim3(1), dim3(1024), 0, L.stream, d, 1 << 30);
+            HIPCHECK_L(L, hipMemcpyAsync(&L.active, L.active_dev.p, 4, hipMemcpyDeviceToHost, L.stream));
         }
-        if (e->tapes)         // finished games need no further tape
-            HIPCHECK(e, hipMemcpyAsync(e->tapes->h_done, e->g_nply.p, (size_t)r.num_games * 4, hipMemcpyDeviceToHost, e->stream));
-        HIPCHECK(e, hipStreamSynchronize(e->stream));
-        HIPCHECK(e, hipGetLastError());
-        e->plies_played++;
+        if (e->tapes)         // finished games need no further tape (g_nply only ever goes from 0 to the game's length, so
+                              // a snapshot that lands late can only cost the producer some extra work)
+            HIPCHECK_L(L, hipMemcpyAsync(e->tapes->h_done, e->g_nply.p, (size_t)r.num_games * 4, hipMemcpyDeviceToHost, L.stream));
+        HIPCHECK_L(L, hipStreamSynchronize(L.stream));
+        HIPCHECK_L(L, hipGetLastError());
+        L.plies_played++;
         if (prof) {
             for (int i = 0; i <= S; i++) {
                 float a = 0.f, b = 0.f, c = 0.f;
-                HIPCHECK(e, hipEventElapsedTime(&a, e->ev[4 * i], e->ev[4 * i + 1]));
-                HIPCHECK(e, hipEventElapsedTime(&b, e->ev[4 * i + 1], e->ev[4 * i + 2]));
-                HIPCHECK(e, hipEventElapsedTime(&c, e->ev[4 * i + 2], e->ev[4 * i + 3]));
-                r.trunk_ms += a;
-                r.nn_ms += a + b;
-                r.step_ms += c;
+                HIPCHECK_L(L, hipEventElapsedTime(&a, L.ev[4 * i], L.ev[4 * i + 1]));
+                HIPCHECK_L(L, hipEventElapsedTime(&b, L.ev[4 * i + 1], L.ev[4 * i + 2]));
+                HIPCHECK_L(L, hipEventElapsedTime(&c, L.ev[4 * i + 2], L.ev[4 * i + 3]));
+                L.trunk_ms += a;
+                L.nn_ms += a + b;
+                L.step_ms += c;
             }
         }
     }
+    return AZ_OK;
+}
+
+// every lane plays up to max_steps plies, each on its own host thread (the caller's thread drives lane 0).  With
+// profiling on the lanes play one after another instead, so that the HIP events time each kernel alone on the GPU.
+static int episode_plies(az_engine *e, int max_steps)
+{
+    az_engine::Run &r = e->run;
+    if (!r.open) return fail(e, AZ_ERR_STATE, "no episode is open");
+    const int K = (int)e->lanes.size();
+    const bool sequential = K == 1 || (e->profile && r.profile);
+    auto t0 = std::chrono::steady_clock::now();
+    if (sequential) {
+        for (Lane &L : e->lanes)
+            if (lane_plies(e, L, max_steps)) break;
+    } else {
+        std::vector<std::thread> th;
+        const int dev = e->cfg.device;
+        for (int i = 1; i < K; i++)
+            th.emplace_back([e, i, max_steps, dev]() {
+                Lane &L = e->lanes[i];
+                if (hipSetDevice(dev) != hipSuccess) { lane_fail(L, AZ_ERR_HIP, "hipSetDevice(%d) failed on a lane thread", dev); return; }
+                lane_plies(e, L, max_steps);
+            });
+        lane_plies(e, e->lanes[0], max_steps);
+        for (auto &t : th) t.join();
+    }
     auto t1 = std::chrono::steady_clock::now();
     r.c.seconds += std::chrono::duration<double>(t1 - t0).count();
+    for (Lane &L : e->lanes)
+        if (L.rc) return fail(e, L.rc, "lane %d: %s", L.index, L.err.c_str());
     return AZ_OK;
+}
+
+static int active_slots(const az_engine *e)
+{
+    int a = 0;
+    for (const Lane &L : e->lanes) a += L.active;
+    return a;
 }
 
 static int read_counters(az_engine *e, az_counters &c)
 {
-    DevState &d = e->d;
-    std::vector<unsigned long long> hc((size_t)d.B * CNT_STRIDE);
-    HIPCHECK(e, az_memcpy(e->stream, hc.data(), e->cnt.p, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     c.expansions = c.simulations = c.terminal_hits = c.depth_sum = 0;
+    c.steps = c.trunk_launches = c.plies = 0;
     int64_t reused = 0;
-    for (int b = 0; b < d.B; b++) {
-        c.expansions += (int64_t)hc[(size_t)b * CNT_STRIDE + 0];
-        c.simulations += (int64_t)hc[(size_t)b * CNT_STRIDE + 1];
-        c.terminal_hits += (int64_t)hc[(size_t)b * CNT_STRIDE + 2];
-        c.depth_sum += (int64_t)hc[(size_t)b * CNT_STRIDE + 3];
-        reused += (int64_t)hc[(size_t)b * CNT_STRIDE + 4];
+    double trunk_ms = 0.0, nn_ms = 0.0, step_ms = 0.0;
+    for (Lane &L : e->lanes) {
+        std::vector<unsigned long long> hc((size_t)L.d.B * CNT_STRIDE);
+        HIPCHECK(e, az_memcpy(L.stream, hc.data(), L.cnt.p, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (int b = 0; b < L.d.B; b++) {
+            c.expansions += (int64_t)hc[(size_t)b * CNT_STRIDE + 0];
+            c.simulations += (int64_t)hc[(size_t)b * CNT_STRIDE + 1];
+            c.terminal_hits += (int64_t)hc[(size_t)b * CNT_STRIDE + 2];
+            c.depth_sum += (int64_t)hc[(size_t)b * CNT_STRIDE + 3];
+            reused += (int64_t)hc[(size_t)b * CNT_STRIDE + 4];
+        }
+        c.steps += L.steps; c.trunk_launches += L.trunk_launches; c.plies += L.plies;
+        trunk_ms += L.trunk_ms; nn_ms += L.nn_ms; step_ms += L.step_ms;
     }
     e->run.reused_roots = reused;
-    c.trunk_seconds = e->run.trunk_ms * 1e-3;
-    c.nn_seconds = e->run.nn_ms * 1e-3;
-    c.step_seconds = e->run.step_ms * 1e-3;
+    c.trunk_seconds = trunk_ms * 1e-3;
+    c.nn_seconds = nn_ms * 1e-3;
+    c.step_seconds = step_ms * 1e-3;
     c.root_evals = c.plies - reused;      // a retained root (subtree reuse) is not evaluated again
     c.records = c.plies;
     c.trunk_boards = c.expansions + c.root_evals;
@@ -803,12 +921,15 @@ static int episode_end(az_engine *e, az_counters *out)
         e->h_nply[0] = 1;   // az_search plays exactly one ply; the game itself is not finished by it
     } else {
         // games still in flight when the caller stops early: report the plies played so far
-        std::vector<int> sg(e->d.B), sp(e->d.B), ss(e->d.B);
-        HIPCHECK(e, az_memcpy(e->stream, sg.data(), e->s_game.p, sg.size() * 4, hipMemcpyDeviceToHost));
-        HIPCHECK(e, az_memcpy(e->stream, sp.data(), e->s_ply.p, sp.size() * 4, hipMemcpyDeviceToHost));
-        HIPCHECK(e, az_memcpy(e->stream, ss.data(), e->s_status.p, ss.size() * 4, hipMemcpyDeviceToHost));
-        for (int b = 0; b < e->d.B; b++)
-            if (ss[b] == SLOT_ACTIVE && sg[b] >= 0 && sg[b] < r.num_games) e->h_nply[sg[b]] = sp[b];
+        for (Lane &L : e->lanes) {
+            const int B = L.d.B;
+            std::vector<int> sg(B), sp(B), ss(B);
+            HIPCHECK(e, az_memcpy(L.stream, sg.data(), L.s_game.p, sg.size() * 4, hipMemcpyDeviceToHost));
+            HIPCHECK(e, az_memcpy(L.stream, sp.data(), L.s_ply.p, sp.size() * 4, hipMemcpyDeviceToHost));
+            HIPCHECK(e, az_memcpy(L.stream, ss.data(), L.s_status.p, ss.size() * 4, hipMemcpyDeviceToHost));
+            for (int b = 0; b < B; b++)
+                if (ss[b] == SLOT_ACTIVE && sg[b] >= 0 && sg[b] < r.num_games) e->h_nply[sg[b]] = sp[b];
+        }
     }
     int64_t plies = 0;
     for (int g = 0; g < r.num_games; g++) plies += e->h_nply[g];
@@ -894,7 +1015,7 @@ extern "C" int az_selfplay_step(az_engine *e, int max_steps, int32_t *active_out
     DEVICE_GUARD(e);
     int rc = episode_plies(e, max_steps);
     if (rc) return rc;
-    if (active_out) *active_out = e->run.active;
+    if (active_out) *active_out = active_slots(e);
     if (progress) {
         az_counters c = e->run.c;
         if ((rc = read_counters(e, c))) return rc;
@@ -987,7 +1108,7 @@ extern "C" int az_selfplay_pack(az_engine *e, void *packed_dev)
     if (src.empty()) return AZ_OK;
     int rc = upload(e, e->src_index, src.data(), src.size() * 4);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_pack, dim3((unsigned)src.size()), dim3(64), 0, e->stream, e->d, (const int *)e->src_index.p,
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)src.size()), dim3(64), 0, e->stream, e->lanes[0].d, (const int *)e->src_index.p,
                        (int64_t)src.size(), nn, record_bytes(nn), (unsigned char *)packed_dev);
     HIPCHECK(e, hipStreamSynchronize(e->stream));
     HIPCHECK(e, hipGetLastError());
@@ -1027,7 +1148,8 @@ extern "C" int az_net_eval(az_engine *e, int slot, int count, const uint8_t *boa
     if (!e->net[slot].loaded) return fail(e, AZ_ERR_NO_WEIGHTS, "weights slot %d not loaded", slot);
     if (e->run.open) return fail(e, AZ_ERR_STATE, "az_net_eval: a self-play episode is open on this engine");
     DEVICE_GUARD(e);
-    const int nn = e->nn, B = e->d.B;
+    Lane &L = e->lanes[0];            // single-position and batch evaluation calls use lane 0
+    const int nn = e->nn, B = L.d.B;
     DevBuf dpol, dval;
     int rc = dev_alloc(e, dpol, (size_t)B * nn * 4);
     if (!rc) rc = dev_alloc(e, dval, (size_t)B * 4);
@@ -1042,29 +1164,29 @@ extern "C" int az_net_eval(az_engine *e, int slot, int count, const uint8_t *boa
             for (int q = 0; q < 4; q++) { lf[(size_t)i * 8 + q] = xm ? x[q] : o[q]; lf[(size_t)i * 8 + 4 + q] = xm ? o[q] : x[q]; }
             kind[i] = LEAF_ROOT; st[i] = SLOT_ACTIVE; ll[i] = lasts[c0 + i];
         }
-        hipError_t hr = az_memcpy(e->stream, e->leaf.p, lf.data(), lf.size() * 8, hipMemcpyHostToDevice);
-        if (hr == hipSuccess) hr = az_memcpy(e->stream, e->leaf_kind.p, kind.data(), (size_t)B * 4, hipMemcpyHostToDevice);
-        if (hr == hipSuccess) hr = az_memcpy(e->stream, e->s_status.p, st.data(), (size_t)B * 4, hipMemcpyHostToDevice);
-        if (hr == hipSuccess) hr = az_memcpy(e->stream, e->s_net.p, nets.data(), (size_t)B * 4, hipMemcpyHostToDevice);
-        if (hr == hipSuccess) hr = az_memcpy(e->stream, e->leaf_last.p, ll.data(), (size_t)B * 4, hipMemcpyHostToDevice);
+        hipError_t hr = az_memcpy(e->stream, L.leaf.p, lf.data(), lf.size() * 8, hipMemcpyHostToDevice);
+        if (hr == hipSuccess) hr = az_memcpy(e->stream, L.leaf_kind.p, kind.data(), (size_t)B * 4, hipMemcpyHostToDevice);
+        if (hr == hipSuccess) hr = az_memcpy(e->stream, L.s_status.p, st.data(), (size_t)B * 4, hipMemcpyHostToDevice);
+        if (hr == hipSuccess) hr = az_memcpy(e->stream, L.s_net.p, nets.data(), (size_t)B * 4, hipMemcpyHostToDevice);
+        if (hr == hipSuccess) hr = az_memcpy(e->stream, L.leaf_last.p, ll.data(), (size_t)B * 4, hipMemcpyHostToDevice);
         if (hr != hipSuccess) { rc = fail(e, AZ_ERR_HIP, "az_net_eval upload: %s", hipGetErrorString(hr)); break; }
         {
-            const LaunchCtx lc = ctx_of_impl(e);
-            if (e->split_max > 0 && e->scratch.p && cnt <= e->split_max) e->ops->trunk_split(lc, slot); else e->ops->trunk(lc, slot);
+            const LaunchCtx lc = ctx_of_impl(e, L);
+            if (e->split_max > 0 && L.scratch.p && cnt <= e->split_max) e->ops->trunk_split(lc, slot); else e->ops->trunk(lc, slot);
             e->ops->fc(lc, slot);
             e->ops->eval_tail(lc, cnt, (float *)dpol.p, (float *)dval.p);
         }
         hr = hipStreamSynchronize(e->stream);
         if (hr == hipSuccess) hr = hipGetLastError();
         if (hr == hipSuccess && logits)
-            hr = az_memcpy2d(e->stream, logits + (size_t)c0 * nn, (size_t)nn * 4, e->logits.p, (size_t)e->RW * 4, (size_t)nn * 4, cnt, hipMemcpyDeviceToHost);
+            hr = az_memcpy2d(e->stream, logits + (size_t)c0 * nn, (size_t)nn * 4, L.logits.p, (size_t)e->RW * 4, (size_t)nn * 4, cnt, hipMemcpyDeviceToHost);
         if (hr == hipSuccess && policy) hr = az_memcpy(e->stream, policy + (size_t)c0 * nn, dpol.p, (size_t)cnt * nn * 4, hipMemcpyDeviceToHost);
         if (hr == hipSuccess && value) hr = az_memcpy(e->stream, value + c0, dval.p, (size_t)cnt * 4, hipMemcpyDeviceToHost);
         if (hr != hipSuccess) { rc = fail(e, AZ_ERR_HIP, "az_net_eval: %s", hipGetErrorString(hr)); break; }
     }
     // leave the slots idle
-    (void)hipMemsetAsync(e->s_status.p, 0, e->s_status.bytes, e->stream);
-    (void)hipMemsetAsync(e->leaf_kind.p, 0, e->leaf_kind.bytes, e->stream);
+    (void)hipMemsetAsync(L.s_status.p, 0, L.s_status.bytes, e->stream);
+    (void)hipMemsetAsync(L.leaf_kind.p, 0, L.leaf_kind.bytes, e->stream);
     (void)hipStreamSynchronize(e->stream);
     dev_free(dpol);
     dev_free(dval);
@@ -1099,18 +1221,19 @@ extern "C" int az_search(az_engine *e, int slot, const uint8_t *board, int playe
     HIPCHECK(e, az_memcpy(e->stream, e->u.p, hu.data(), hu.size() * 8, hipMemcpyHostToDevice));
     u64 bd[8];
     planes_from_cells(board, nn, bd, bd + 4);
-    HIPCHECK(e, hipMemsetAsync(e->s_status.p, 0, e->s_status.bytes, e->stream));
-    HIPCHECK(e, hipMemcpyAsync(e->board.p, bd, sizeof bd, hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(k_set_position, dim3(1), dim3(64), 0, e->stream, e->d, 0, 0, player, last, stones);
+    Lane &L0 = e->lanes[0];
+    HIPCHECK(e, hipMemsetAsync(L0.s_status.p, 0, L0.s_status.bytes, e->stream));
+    HIPCHECK(e, hipMemcpyAsync(L0.board.p, bd, sizeof bd, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_set_position, dim3(1), dim3(64), 0, e->stream, L0.d, 0, 0, player, last, stones);
     HIPCHECK(e, hipStreamSynchronize(e->stream));
     EpisodeSpec sp;
     sp.num_games = 1; sp.max_plies = 0; sp.add_noise = noise != nullptr; sp.arena = false; sp.preset = true; sp.profile = false;
     // the arena flag only selects the net through s_player; a search with the baseline net uses slot 1 weights as slot 0
     PackedNet saved0 = e->net[0];
-    const float *sv2w = e->d.v2w[0], *sv2b = e->d.v2b[0];
-    if (slot == 1) { e->net[0] = e->net[1]; e->d.v2w[0] = e->d.v2w[1]; e->d.v2b[0] = e->d.v2b[1]; }
+    const float *sv2w = L0.d.v2w[0], *sv2b = L0.d.v2b[0];
+    if (slot == 1) { e->net[0] = e->net[1]; L0.d.v2w[0] = L0.d.v2w[1]; L0.d.v2b[0] = L0.d.v2b[1]; }
     rc = run_episode(e, sp, nullptr);
-    if (slot == 1) { e->net[0] = saved0; e->d.v2w[0] = sv2w; e->d.v2b[0] = sv2b; }
+    if (slot == 1) { e->net[0] = saved0; L0.d.v2w[0] = sv2w; L0.d.v2b[0] = sv2b; }
     if (rc) return rc;
     // outputs: record 0*nn + stones
     const size_t ri = (size_t)stones;
@@ -1122,7 +1245,7 @@ extern "C" int az_search(az_engine *e, int slot, const uint8_t *board, int playe
     }
     if (visits || W || prior) {
         std::vector<Edge> row(e->RW);
-        HIPCHECK(e, az_memcpy(e->stream, row.data(), e->edges.p, row.size() * sizeof(Edge), hipMemcpyDeviceToHost));
+        HIPCHECK(e, az_memcpy(e->stream, row.data(), L0.edges.p, row.size() * sizeof(Edge), hipMemcpyDeviceToHost));
         for (int j = 0; j < nn; j++) {
             const bool legal = board[j] == 0;
             if (visits) visits[j] = legal ? row[j].N : 0;
@@ -1212,10 +1335,11 @@ extern "C" int az_rules_replay(az_engine *e, int games, int max_len, const int16
 // diagnostic builds (-DAZ_STAMPS): per-workgroup phase stamps of the last k_trunk launch, 16 u64 per workgroup
 extern "C" int az_debug_stamps(az_engine *e, unsigned long long *out, int max_groups)
 {
-    if (!e || !out || !e->dbg.p) return AZ_ERR_STATE;
-    size_t n = std::min<size_t>((size_t)max_groups * 16, e->dbg.bytes / 8);
-    if (max_groups < 0) n = e->dbg.bytes / 8;   // everything (trunk stamps, then k_fc stamps at offset B*16)
-    HIPCHECK(e, az_memcpy(e->stream, out, e->dbg.p, n * 8, hipMemcpyDeviceToHost));
+    if (!e || !out || !e->lanes[0].dbg.p) return AZ_ERR_STATE;
+    DevBuf &dbg = e->lanes[0].dbg;
+    size_t n = std::min<size_t>((size_t)max_groups * 16, dbg.bytes / 8);
+    if (max_groups < 0) n = dbg.bytes / 8;   // everything (trunk stamps, then k_fc stamps at offset B*16)
+    HIPCHECK(e, az_memcpy(e->stream, out, dbg.p, n * 8, hipMemcpyDeviceToHost));
     return AZ_OK;
 }
 
@@ -1240,7 +1364,7 @@ extern "C" int az_set_subtree_reuse(az_engine *e, int on)
     if (e->run.open) return fail(e, AZ_ERR_STATE, "az_set_subtree_reuse: an episode is open");
     if (on && e->R > REUSE_MAX_ROWS)
         return fail(e, AZ_ERR_INVALID, "subtree reuse supports at most %d simulations per move", REUSE_MAX_ROWS - 1);
-    e->d.reuse = on ? 1 : 0;
+    e->reuse = on ? 1 : 0;
     return AZ_OK;
 }
 
@@ -1257,3 +1381,5 @@ extern "C" int az_get_counters(const az_engine *e, az_counters *out)
     *out = e->last;
     return AZ_OK;
 }
+
+extern "C" int az_get_lanes(const az_engine *e) { return e ? (int)e->lanes.size() : AZ_ERR_INVALID; }

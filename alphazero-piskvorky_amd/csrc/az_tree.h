@@ -608,15 +608,18 @@ __global__ __launch_bounds__(256) void k_move(DevState d)
 
 #ifdef AZ_ENGINE_TU
 // ------------------------------------------------------------------------------------------------
-// k_refill: finished/idle slots receive the next game ids in slot order (ballot + prefix sum),
-//           replacing the task queue of self_play.py:114-118,41-45.  One block of 1024 threads.
+// k_refill: finished/idle slots receive the next game ids in slot order (ballot + prefix sum), replacing the task
+//           queue of self_play.py:114-118,41-45.  The queue is ONE device counter shared by the lanes (streams) of an
+//           engine: a chunk of slots claims its ids with a single atomicAdd, so a slot freed in any lane takes the next
+//           waiting game.  claim_cap bounds the ids this launch may take (the first refill of an episode spreads the
+//           games evenly over the lanes).  One block of 1024 threads.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_refill(DevState d)
+__global__ __launch_bounds__(1024) void k_refill(DevState d, int claim_cap)
 {
     __shared__ int wsum[16];
-    __shared__ int base_s, active_s;
+    __shared__ int base_s, take_s, cap_s, active_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) { base_s = *d.next_game; active_s = 0; }
+    if (tid == 0) { cap_s = claim_cap; active_s = 0; }
     __syncthreads();
     for (int c0 = 0; c0 < d.B; c0 += 1024) {
         int b = c0 + tid;
@@ -629,13 +632,22 @@ __global__ __launch_bounds__(1024) void k_refill(DevState d)
         __syncthreads();
         int off = 0, tot = 0;
         for (int w = 0; w < 16; w++) { off += w < wv ? wsum[w] : 0; tot += wsum[w]; }
-        int base = base_s;
+        if (tid == 0) {
+            int want = min(tot, cap_s), base = 0, got = 0;
+            if (want > 0 && *(volatile int *)d.next_game < d.total_games) {     // an exhausted queue is left alone (no overflow)
+                base = atomicAdd(d.next_game, want);
+                got = max(0, min(want, d.total_games - base));
+            }
+            base_s = base; take_s = got; cap_s -= want;
+        }
+        __syncthreads();
         int newact = 0;
         if (need) {
-            int gid = base + off + pre;
-            if (gid < d.total_games) {
+            const int idx = off + pre;
+            if (idx < take_s) {
                 u64 *bd = d.board + (size_t)b * 8;
                 for (int q = 0; q < 8; q++) bd[q] = 0ull;
+                const int gid = base_s + idx;
                 d.s_game[b] = gid;
                 d.s_ply[b] = 0;
                 d.s_player[b] = (d.arena && (gid & 1)) ? 2 : 1;   // evaluator.py:64-69
@@ -652,10 +664,8 @@ __global__ __launch_bounds__(1024) void k_refill(DevState d)
         u64 bnew = __ballot(newact != 0);
         if (lane == 0) atomicAdd(&active_s, __popcll(bnew) + __popcll(bact));
         __syncthreads();
-        if (tid == 0) base_s = min(base + tot, d.total_games);
-        __syncthreads();
     }
-    if (tid == 0) { *d.next_game = base_s; *d.active = active_s; }
+    if (tid == 0) *d.active = active_s;
 }
 
 // az_rules_replay: Gomoku.apply_action / is_terminal / get_game_result (games.py:64-82,133-179) for whole action lists,

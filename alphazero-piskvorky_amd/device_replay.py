@@ -12,7 +12,7 @@ from ._capi import AZ_AUG_REFERENCE4
 
 class DeviceReplayBuffer:
     def __init__(self, engine, capacity=40_000, aug=AZ_AUG_REFERENCE4, device="cuda:0", seed=None):
-        self.engine = engine.parts[0] if hasattr(engine, "parts") else engine
+        self.engine = engine
         self.aug = aug
         self.rb = self.engine.record_bytes
         self.n = self.engine.n

@@ -7,7 +7,7 @@ import torch
 
 from . import constants as _c
 from . import parallel
-from ._capi import AZ_AUG_REFERENCE4, MultiEngine
+from ._capi import AZ_AUG_REFERENCE4, Engine
 from .controller import device_index, model_kind
 from .mcts import numpy_log_table
 
@@ -29,7 +29,7 @@ class SelfPlayManager:
         self.concurrent_games = concurrent_games or _c.CONCURRENT_GAMES
         self.augmentation = augmentation      # 4 = the reference's rotations (self_play.py:94-108), 8 = full dihedral group, 1 = none
         self.seed = seed
-        self.engines_per_gpu = engines_per_gpu or _c.ENGINES_PER_GPU
+        self.engines_per_gpu = engines_per_gpu      # None: az_config.engines = 0, the library chooses
         self.subtree_reuse = subtree_reuse    # opt-in search upgrade (mcts.py:17-22 TODO); off = the reference's fresh root every move
         self.gather_to = gather_to            # multi-rank: None = every rank receives all records (all-gather); r = only rank r does
         self.last_counters = None
@@ -42,11 +42,10 @@ class SelfPlayManager:
         if self._engine is None or self._engine_key != key:
             if self._engine is not None:
                 self._engine.close()
-            # small boards are launch-bound (one engine), small episodes are not worth splitting
-            engines = 1 if n <= 5 else max(1, min(self.engines_per_gpu, slots // 128))
-            self._engine = MultiEngine(n, k, key[2], slots, engines=engines, c_puct=key[4], dirichlet_alpha=key[5],
-                                       dirichlet_weight=key[6], device=device_index(self.device),
-                                       log_table=numpy_log_table(key[2]), model=key[7])
+            # lanes per GPU: the library's own rule (1 on small boards, one per 128 slots up to 4) unless the caller fixed it
+            self._engine = Engine(n, k, key[2], slots, engines=self.engines_per_gpu or 0, c_puct=key[4], dirichlet_alpha=key[5],
+                                  dirichlet_weight=key[6], device=device_index(self.device),
+                                  log_table=numpy_log_table(key[2]), model=key[7])
             self._engine_key = key
         return self._engine
 

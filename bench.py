@@ -85,8 +85,11 @@ def main():
     ap.add_argument("--win", type=int, default=5)
     ap.add_argument("--sims", type=int, default=400)
     ap.add_argument("--slots", type=int, default=1024, help="concurrent games per GPU")
-    ap.add_argument("--engines", type=int, default=0, help="engines per GPU (slots are split; driven from host threads so that "
-                    "one engine's tree/FC kernels overlap another's conv trunk); 0 = auto: 1 for 5x5 (launch-bound), 4 otherwise")
+    ap.add_argument("--engines", type=int, default=0, help="lanes inside the engine (az_config.engines: the slots are split over this many HIP "
+                    "streams, each driven by a host thread of the library, so that one lane's tree/FC kernels overlap another's conv trunk); "
+                    "0 = the library's rule: 1 up to 5x5 (launch-bound), else one per 128 slots up to 4")
+    ap.add_argument("--steady-games", type=int, default=-1, help="games of the second, steady-state episode (games >> slots, slots refilled "
+                    "from the shared queue); -1 = 3 x slots, 0 = skip")
     ap.add_argument("--model", default="plain", choices=["plain", "resnet"], help="plain = GomokuNet (net.py); resnet = ResidualBlock variant (config 5)")
     ap.add_argument("--no-episode", action="store_true", help="skip playing the episode to its end")
     ap.add_argument("--subtree-reuse", action="store_true", help="opt-in search upgrade (not the reference's algorithm): keep the chosen child's subtree between plies")
@@ -118,10 +121,9 @@ def main():
     from alphazero_piskvorky_amd import parallel
 
     n, k, S, B = a.board, a.win, (8 if a.pmc_run else a.sims), a.slots
-    if a.engines <= 0:
-        a.engines = 1 if n <= 5 else 4
     sd = synthetic_resnet_state_dict(n) if a.model == "resnet" else synthetic_state_dict(n)
-    eng = az.MultiEngine(n, k, S, B, engines=a.engines, device=local, model=a.model)
+    eng = az.Engine(n, k, S, B, engines=a.engines, device=local, model=a.model)
+    a.engines = eng.lanes()
     eng.load_weights(sd, 0)
     if a.subtree_reuse:
         eng.set_subtree_reuse(True)
@@ -136,11 +138,13 @@ def main():
 
     if a.warmup > 0:
         eng.selfplay_step(a.warmup)
-    # roofline calibration: ONE engine plays one ply while the others idle, so the HIP events around its trunk
-    # launches time the kernel alone on the GPU (with several engines the launches of different streams overlap)
+    # roofline calibration: one ply with az_set_profiling on -- the lanes then play one after another, so the HIP
+    # events around every launch time the kernel alone on the GPU (normally the launches of different lanes overlap)
     barrier()
-    _, k0 = eng.step_one_engine(0, 0)
-    _, k1 = eng.step_one_engine(0, 1, profile=True)
+    _, k0 = eng.selfplay_step(0)
+    eng.set_profiling(True)
+    _, k1 = eng.selfplay_step(1)
+    eng.set_profiling(False)
     cal = {key: k1[key] - k0[key] for key in k1}
     barrier()
     _, c0 = eng.selfplay_step(0)
@@ -181,9 +185,25 @@ def main():
             td.all_reduce(tot, op=td.ReduceOp.SUM)
         ep_s, tg_s = [float(x) for x in ep.tolist()]
         g_all, e_all, p_all = [float(x) for x in tot.tolist()]
-        episode = {"games": int(g_all), "seconds": ep_s, "games_per_sec": g_all / ep_s,
+        episode = {"what": f"one episode of {B} games per GPU on {B} slots (BASELINE's shape): no refill, the slots of finished games idle "
+                           "until the longest game ends",
+                   "games": int(g_all), "seconds": ep_s, "games_per_sec": g_all / ep_s,
                    "node_expansions_per_sec": e_all / ep_s, "mean_plies_per_game": p_all / g_all,
                    "record_gather_seconds": tg_s, "records_gathered": int(sum(counts))}
+        # ---- steady state: games >> slots, every freed slot takes the next game of the engine's shared queue ----
+        sg = a.steady_games if a.steady_games >= 0 else 3 * B
+        if sg > 0:
+            del packed
+            cs = eng.selfplay(sg, seed0=2_000_000 + rank * sg)
+            st = torch.tensor([cs["seconds"]], dtype=torch.float64, device=cdev)
+            tot = torch.tensor([cs["games"], cs["expansions"] + cs["plies"]], dtype=torch.float64, device=cdev)
+            if dist:
+                td.all_reduce(st, op=td.ReduceOp.MAX)
+                td.all_reduce(tot, op=td.ReduceOp.SUM)
+            episode["steady_state"] = {"what": f"a second episode of {sg} games per GPU on the same {B} slots, freed slots refilled from the shared queue",
+                                       "games": int(tot[0].item()), "seconds": float(st.item()),
+                                       "games_per_sec": float(tot[0].item() / st.item()),
+                                       "node_expansions_per_sec": float(tot[1].item() / st.item())}
     else:
         eng.selfplay_end()
 
@@ -211,7 +231,7 @@ def main():
         nn_cells = n * n
         ply_index = a.warmup                                  # plies already played when the calibration ply starts
         A = nn_cells - ply_index
-        games_cal = max(cal["plies"], 1)                      # games the calibrating engine holds (one ply each)
+        games_cal = max(cal["plies"] / max(a.engines, 1), 1)  # games per launch: every lane plays its own slots (one ply each)
         dbar = cal["depth_sum"] / max(cal["simulations"], 1)
         step_launches = max(cal["steps"], 1)
         bytes_sim = dbar * (12 * A + 16) + 12 * A + (2 * ((nn_cells + 7) // 8) + 2) + (4 * nn_cells + 4)
@@ -246,14 +266,15 @@ def main():
             "simulations_per_sec": sims_all / dt, "plies_per_sec": plies_all / dt,
             "mean_select_depth": depth_all / max(sims_all, 1), "terminal_hit_fraction": term_all / max(sims_all, 1),
             "self_play_games_per_sec": None if episode is None else episode["games_per_sec"],
+            "self_play_games_per_sec_steady_state": None if episode is None or "steady_state" not in episode else episode["steady_state"]["games_per_sec"],
             "episode": episode,
             "roofline": {"kernel": (f"k_trunk<{n}> (encode+conv1+conv2+conv3+head convs, LDS-resident, v_mfma_f32_16x16x4_f32)" if a.model == "plain"
                                     else f"k_trunk_res<{n}> (encode+stem+3 residual blocks+head convs, LDS-resident, v_mfma_f32_16x16x4_f32)"),
                          "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": avg_ms, "boards_per_launch": boards / launches,
                          "flops_per_board": trunk_f,
-                         "measured": "HIP events around every k_trunk launch of one calibration ply played by a single engine "
-                                     "(other engines idle), between warmup and the timed region",
+                         "measured": "HIP events around every k_trunk launch of one calibration ply (az_set_profiling: the lanes play "
+                                     "one after another, every launch alone on the GPU), between warmup and the timed region",
                          "rest": rest,
                          "aggregate": {"achieved": agg, "frac": agg / peak, "unit": "TFLOP/s",
                                        "what": "trunk FLOPs per wall second over the timed region, all engines/streams overlapping "

@@ -12,7 +12,9 @@
  * Conventions: every call returns 0 on success or a negative az_status; nothing throws
  * or aborts across the boundary; the caller owns all input buffers; outputs are written
  * into caller-provided buffers; one engine per GPU; calls on one engine are serialised by
- * the caller; engines on different GPUs are independent.  Pointers suffixed _dev are
+ * the caller (the engine runs its own host threads inside a call, one per lane, and joins them
+ * before returning); engines on different GPUs are independent; the calling thread's current
+ * HIP device is left as it was.  Pointers suffixed _dev are
  * device pointers (e.g. torch tensor.data_ptr()), all others are host pointers.
  *
  * The library contains NO CPU implementation of the path: az_create fails with
@@ -60,6 +62,13 @@ typedef struct {
        NULL -> computed with libm logf.                                                          */
     const float *log_table;
     int32_t model;             /* AZ_MODEL_PLAIN (net.py:16-72) | AZ_MODEL_RESNET (config 5)                         */
+    /* Lanes inside the engine: the slots are split over `engines` HIP streams, each driven by its own host thread inside
+       the library, so that one lane's latency-bound tree / FC kernels run underneath another lane's conv trunk.  All lanes
+       take their games from one shared queue (a freed slot of any lane gets the next waiting game) and write into the
+       same per-game records, so the episode is the same whatever the number of lanes.  0 = the library chooses
+       (1 for boards up to 5x5, else one lane per 128 slots up to 4).  Replaces the worker processes of
+       self_play.py:29-45,122-136 (NUM_WORKERS, constants.py:6). */
+    int32_t engines;
 } az_config;
 
 /* ---- lifecycle ---- */
@@ -214,10 +223,15 @@ int az_rng_uniforms(uint64_t seed, int count, double *u);
 int az_set_subtree_reuse(az_engine *e, int on);
 
 /* HIP-event timing of every trunk / FC / tree-step launch (az_counters.trunk_seconds, nn_seconds, step_seconds);
- * off by default: four events per evaluation batch cost a few microseconds of stream time, which matters on small boards. */
+ * off by default: four events per evaluation batch cost a few microseconds of stream time, which matters on small boards.
+ * While it is on, the lanes of the engine play one after another instead of concurrently, so that every kernel is timed
+ * alone on the GPU (roofline calibration). */
 int az_set_profiling(az_engine *e, int on);
 
 int az_get_counters(const az_engine *e, az_counters *out);
+
+/* Number of lanes the engine runs (az_config.engines after the library's choice for 0). */
+int az_get_lanes(const az_engine *e);
 
 #ifdef __cplusplus
 }

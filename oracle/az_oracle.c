@@ -451,6 +451,9 @@ typedef struct {
     const float *log_table;     /* log_table[N] = np.log(float32(N)+1e-8) as float32, N = 0..S; NULL -> logf */
     int reuse;                  /* opt-in subtree reuse between the plies of a self-play game (include/az_engine.h,
                                    az_set_subtree_reuse); 0 = the reference's behaviour (new root every run, mcts.py:106) */
+    int vl;                     /* opt-in virtual-loss batching (include/az_engine.h, az_set_virtual_loss): leaves selected per
+                                   evaluation batch; 0 = the reference's sequential loop (mcts.py:123-141).  vl = 1 runs the
+                                   batched code with batches of one, which must reproduce the reference exactly. */
 } orc_cfg;
 
 typedef struct {
@@ -459,6 +462,7 @@ typedef struct {
     int N;          /* mcts.py:37 */
     double W;       /* mcts.py:38 */
     int first, cnt; /* children block (insertion = row-major legal order, mcts.py:58) */
+    int vl;         /* virtual-loss mode only: simulations of the current batch that pass through this node */
 } orc_node;
 
 typedef struct {
@@ -466,6 +470,7 @@ typedef struct {
     long expansions, sims, terminal_hits, depth_sum;
     int retained;               /* subtree reuse: nodes[0] is an already expanded root kept from the previous ply */
     long reused_roots;
+    long dup_sims;              /* virtual-loss mode: simulations that landed on a leaf already pending in their batch */
 } orc_tree;
 
 static void evaluate(const orc_cfg *cfg, const orc_net *net, const orc_state *s, float *P, float *v)
@@ -486,7 +491,7 @@ static void expand(orc_tree *t, int node, const orc_state *s, const float *P)
     for (int a = 0; a < nn; a++) {
         if (s->cell[a]) continue;
         orc_node *c = &t->nodes[t->used++];
-        c->parent = node; c->action = a; c->prior = (double)P[a]; c->N = 0; c->W = 0.0; c->first = -1; c->cnt = 0;
+        c->parent = node; c->action = a; c->prior = (double)P[a]; c->N = 0; c->W = 0.0; c->first = -1; c->cnt = 0; c->vl = 0;
         cnt++;
     }
     t->nodes[node].cnt = cnt;
@@ -584,7 +589,7 @@ static int mcts_run(const orc_cfg *cfg, const orc_net *net, const orc_state *roo
         t->reused_roots++;
     } else {
     t->used = 1;
-    root->parent = -1; root->action = -1; root->prior = 1.0; root->N = 0; root->W = 0.0; root->first = -1; root->cnt = 0;
+    root->parent = -1; root->action = -1; root->prior = 1.0; root->N = 0; root->W = 0.0; root->first = -1; root->cnt = 0; root->vl = 0;
 
     evaluate(cfg, net, root_state, P, &v);            /* mcts.py:109 (root value discarded) */
     if (noise) {                                      /* mcts.py:113-116, arithmetic per SURVEY Q8 */
@@ -600,6 +605,78 @@ static int mcts_run(const orc_cfg *cfg, const orc_net *net, const orc_state *roo
     expand(t, 0, root_state, P);                      /* mcts.py:120 */
     }
     int maxd = 0;
+    if (cfg->vl > 0) {
+        /* Virtual-loss batching (NOT in the reference; its TODO list names it, mcts.py:17-22).  The S simulations run in
+         * batches of L = cfg->vl: the L leaves of a batch are selected one after another from the same tree, each
+         * selection seeing the earlier ones of its batch as one visit that lost (N + 1, W - 1 on every edge of their
+         * paths); then the batch is evaluated together, and the simulations are finished in selection order: the virtual
+         * visit is taken back, the leaf is expanded and its value backed up exactly like mcts.py:136-141.  A selection
+         * that ends on a leaf an earlier simulation of the batch is already waiting on ("duplicate") does not evaluate or
+         * expand again; it backs up that leaf's value.  Terminal leaves are scored at once as in mcts.py:132-134. */
+        enum { VL_MAX = 32 };
+        const int L = cfg->vl > VL_MAX ? VL_MAX : cfg->vl;
+        int leaf[VL_MAX], kind[VL_MAX], dup_of[VL_MAX], depth_of[VL_MAX];   /* kind: 0 expand, 1 terminal, 2 duplicate */
+        double tval[VL_MAX];
+        float vals[VL_MAX];
+        static __thread float Pb[VL_MAX][ORC_MAXNN];
+        static __thread orc_state sb[VL_MAX];
+        for (int done = first_sim; done < cfg->S; ) {
+            const int nb = cfg->S - done < L ? cfg->S - done : L;
+            for (int j = 0; j < nb; j++) {
+                int node = 0, depth = 0;
+                orc_state s = *root_state;
+                s.winner = root_state->winner;
+                while (t->nodes[node].cnt > 0 && !st_terminal(&s)) {
+                    const orc_node *nd = &t->nodes[node];
+                    double sq = sqrt((double)(nd->N + nd->vl) + 1e-8);
+                    int best = -1; double bs = 0.0;
+                    for (int i = 0; i < nd->cnt; i++) {
+                        const orc_node *c = &t->nodes[nd->first + i];
+                        int Nv = c->N + c->vl;
+                        double Wv = c->W - (double)c->vl;
+                        double Q = Nv ? Wv / (double)Nv : 0.0;
+                        double sc = Q + ((cfg->c_puct * c->prior) * sq) / (double)(1 + Nv);
+                        if (best < 0 || sc > bs) { best = i; bs = sc; }
+                    }
+                    node = nd->first + best;
+                    st_apply(&s, t->nodes[node].action);
+                    depth++;
+                }
+                leaf[j] = node; depth_of[j] = depth; dup_of[j] = -1;
+                if (st_terminal(&s)) {
+                    kind[j] = 1;
+                    tval[j] = s.winner == RES_DRAW ? 0.0 : (s.winner == s.player ? 1.0 : -1.0);
+                } else {
+                    kind[j] = 0;
+                    for (int i = 0; i < j; i++)
+                        if (kind[i] == 0 && leaf[i] == node) { kind[j] = 2; dup_of[j] = i; break; }
+                    if (kind[j] == 0) sb[j] = s;
+                }
+                for (int nd = node; nd >= 0; nd = t->nodes[nd].parent) t->nodes[nd].vl += 1;
+            }
+            for (int j = 0; j < nb; j++)
+                if (kind[j] == 0) evaluate(cfg, net, &sb[j], Pb[j], &vals[j]);
+            for (int j = 0; j < nb; j++) {
+                const int node = leaf[j];
+                for (int nd = node; nd >= 0; nd = t->nodes[nd].parent) t->nodes[nd].vl -= 1;
+                double value;
+                if (kind[j] == 1) { value = tval[j]; t->terminal_hits++; }
+                else if (kind[j] == 0) { expand(t, node, &sb[j], Pb[j]); value = (double)vals[j]; t->expansions++; }
+                else { value = (double)vals[dup_of[j]]; t->dup_sims++; }
+                if (depth_of[j] > maxd) maxd = depth_of[j];
+                t->sims++; t->depth_sum += depth_of[j];
+                double val = -value;
+                for (int nd = node; nd >= 0; nd = t->nodes[nd].parent) {
+                    t->nodes[nd].N += 1;
+                    t->nodes[nd].W += val;
+                    val = -val;
+                }
+            }
+            done += nb;
+        }
+        if (maxdepth_out) *maxdepth_out = maxd;
+        return extract_policy(cfg, t, nn, T, u, pi_out);
+    }
     for (int sim = first_sim; sim < cfg->S; sim++) {  /* mcts.py:123 */
         int node = 0, depth = 0;
         orc_state s = *root_state;                    /* clone */
@@ -739,7 +816,7 @@ int orc_selfplay_game(const orc_cfg *cfg, const orc_net *net, const double *nois
     for (int i = 0; i < m; i++)                              /* self_play.py:71 */
         z[i] = (int8_t)(res == RES_NONE ? 99 : (res == RES_DRAW ? 0 : (movers[i] == res ? 1 : -1)));
     if (result_out) *result_out = res;
-    if (counters) { counters[0] = t->expansions; counters[1] = t->sims; counters[2] = t->terminal_hits; counters[3] = t->depth_sum; counters[4] = m - t->reused_roots; }
+    if (counters) { counters[0] = t->expansions; counters[1] = t->sims; counters[2] = t->terminal_hits; counters[3] = t->depth_sum; counters[4] = m - t->reused_roots; counters[5] = t->dup_sims; }
     tree_free(t);
     return m;
 }

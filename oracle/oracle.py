@@ -33,7 +33,7 @@ def build(force=False):
 class _Cfg(C.Structure):
     _fields_ = [("n", C.c_int), ("k", C.c_int), ("S", C.c_int),
                 ("c_puct", C.c_double), ("alpha", C.c_double), ("w", C.c_double),
-                ("eval_kind", C.c_int), ("log_table", C.POINTER(C.c_float)), ("reuse", C.c_int)]
+                ("eval_kind", C.c_int), ("log_table", C.POINTER(C.c_float)), ("reuse", C.c_int), ("vl", C.c_int)]
 
 
 def lib():
@@ -116,11 +116,11 @@ class Net:
 
 
 class Oracle:
-    def __init__(self, n, k, S, c_puct=2.0, alpha=0.3, w=0.25, synthetic=False, log_table=None, reuse=False):
+    def __init__(self, n, k, S, c_puct=2.0, alpha=0.3, w=0.25, synthetic=False, log_table=None, reuse=False, virtual_loss=0):
         self.n, self.k, self.S = n, k, S
         self.log_table = numpy_log_table(max(S, 1)) if log_table is None else np.ascontiguousarray(log_table, np.float32)
         self.cfg = _Cfg(n, k, S, c_puct, alpha, w, 1 if synthetic else 0,
-                        self.log_table.ctypes.data_as(C.POINTER(C.c_float)), 1 if reuse else 0)
+                        self.log_table.ctypes.data_as(C.POINTER(C.c_float)), 1 if reuse else 0, int(virtual_loss))
 
     # ---- rules ----
     def replay(self, actions):
@@ -170,7 +170,7 @@ class Oracle:
         return dict(nply=m, boards=boards[:m], movers=movers[:m], lasts=lasts[:m], pis=pis[:m], visits=visits[:m],
                     actions=actions[:m], z=z[:m], result=res.value,
                     counters=dict(expansions=int(counters[0]), sims=int(counters[1]), terminal_hits=int(counters[2]),
-                                  depth_sum=int(counters[3]), root_evals=int(counters[4])))
+                                  depth_sum=int(counters[3]), root_evals=int(counters[4]), dup_sims=int(counters[5])))
 
     def arena_game(self, cand, base, game_index, u_tape, T_table=None):
         nn = self.n * self.n

@@ -331,3 +331,58 @@ def test_explicit_tape_shorter_than_the_plies_is_rejected():
     c = e.selfplay(G, max_plies=3, noise_tape=np.full((G, three), 1.0 / nn), u_tape=us)   # exactly 3 plies of tape: accepted
     assert c["plies"] == 3 * G
     e.close()
+
+
+@pytest.mark.parametrize("synthetic", [True, False])
+def test_lanes_inside_the_library_give_the_single_lane_episode(synthetic):
+    """az_config.engines: the slots split over K streams + K host threads inside ONE az_selfplay call, all lanes claiming
+    game ids from one shared device queue.  Games are seeded per id and recorded per id, so records, outcomes and the
+    work counters are identical for every K -- also with far more games than slots (refill through the shared queue),
+    for the arena, and for a single-position search on a multi-lane engine."""
+    n, k, S, G = 9, 5, 24, 45
+    sd = weights_from_fixture(n, "seeded")
+    out = {}
+    for K in (1, 3, 4):
+        e = az.Engine(n, k, S, 12, engines=K, synthetic=synthetic, log_table=orc.numpy_log_table(S))
+        assert e.lanes() == K
+        if not synthetic:
+            e.load_weights(sd, 0); e.load_weights(weights_from_fixture(n, "seeded"), 1)
+        c = e.selfplay(G, seed0=77, max_plies=0 if synthetic else 4)
+        rec = e.records(); nply, res = e.games()
+        arena = e.arena(7, seed0=5, temperature_table=orc.arena_T_table(n * n)) if synthetic else None
+        board = np.zeros(n * n, np.uint8); board[40] = 1
+        srch = e.search(board, 2, 40, 0.7, None, 0.3)
+        out[K] = (rec, nply, res, c, arena, srch)
+        e.close()
+    ref = out[1]
+    for K in (3, 4):
+        rec, nply, res, c, arena, srch = out[K]
+        for key in ref[0]:
+            assert np.array_equal(ref[0][key], rec[key]), f"K={K}: {key}"
+        assert np.array_equal(ref[1], nply) and np.array_equal(ref[2], res)
+        for key in ("games", "plies", "records", "simulations", "expansions", "root_evals", "terminal_hits", "depth_sum"):
+            assert ref[3][key] == c[key], f"K={K}: counter {key}"
+        if arena is not None:
+            for key in ("wins", "losses", "draws", "total"):
+                assert ref[4][key] == arena[key]
+            assert np.array_equal(ref[4]["actions"], arena["actions"]) and np.array_equal(ref[4]["results"], arena["results"])
+        assert np.array_equal(ref[5]["N"], srch["N"]) and ref[5]["action"] == srch["action"]
+
+
+def test_auto_lanes_and_lane_limits():
+    e = az.Engine(5, 4, 8, 1024, synthetic=True)
+    assert e.lanes() == 1                        # small boards are launch-bound: one lane
+    e.close()
+    e = az.Engine(9, 5, 8, 1024, synthetic=True)
+    assert e.lanes() == 4                        # one lane per 128 slots, at most four
+    e.close()
+    e = az.Engine(9, 5, 8, 200, synthetic=True)
+    assert e.lanes() == 1
+    e.close()
+    e = az.Engine(9, 5, 8, 3, engines=8, synthetic=True)
+    assert e.lanes() == 3                        # never an empty lane
+    c = e.selfplay(5, seed0=1, max_plies=2)
+    assert c["plies"] == 10
+    e.close()
+    with pytest.raises(az.AzError):
+        az.Engine(9, 5, 8, 64, engines=17, synthetic=True)
