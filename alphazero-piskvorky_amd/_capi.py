@@ -27,7 +27,7 @@ AZ_MODEL_PLAIN, AZ_MODEL_RESNET = 0, 1
 EXPORTS = [
     "az_create", "az_destroy", "az_last_error", "az_load_weights", "az_load_weights_resnet", "az_net_eval", "az_search", "az_selfplay",
     "az_selfplay_begin", "az_selfplay_step", "az_selfplay_end", "az_selfplay_games", "az_selfplay_records", "az_record_bytes", "az_selfplay_pack", "az_examples_from_packed",
-    "az_examples_gather", "az_arena", "az_rules_replay", "az_rng_selfplay_tape", "az_rng_uniforms", "az_set_profiling", "az_set_subtree_reuse", "az_get_counters", "az_get_lanes",
+    "az_examples_gather", "az_arena", "az_rules_replay", "az_rng_selfplay_tape", "az_rng_uniforms", "az_set_profiling", "az_set_subtree_reuse", "az_get_counters", "az_get_lanes", "az_set_virtual_loss", "az_set_eval_cache",
 ]
 
 
@@ -53,7 +53,8 @@ class az_counters(C.Structure):
                 ("expansions", C.c_int64), ("root_evals", C.c_int64), ("terminal_hits", C.c_int64),
                 ("depth_sum", C.c_int64), ("steps", C.c_int64), ("seconds", C.c_double), ("nn_seconds", C.c_double),
                 ("trunk_seconds", C.c_double), ("trunk_launches", C.c_int64), ("trunk_boards", C.c_int64),
-                ("step_seconds", C.c_double)]
+                ("step_seconds", C.c_double), ("duplicate_leaves", C.c_int64), ("cache_lookups", C.c_int64),
+                ("cache_hits", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -323,6 +324,15 @@ class Engine:
     def set_subtree_reuse(self, on):
         """Opt-in: keep the chosen child's subtree for the next ply (mcts.py:17-22 TODO); see include/az_engine.h."""
         self._check(lib().az_set_subtree_reuse(self.h, 1 if on else 0), "az_set_subtree_reuse")
+
+    def set_virtual_loss(self, leaves):
+        """Opt-in: virtual-loss batching, `leaves` leaves per search and evaluation batch (mcts.py:17-22 TODO); 1 = the
+        reference's sequential loop.  See include/az_engine.h."""
+        self._check(lib().az_set_virtual_loss(self.h, int(leaves)), "az_set_virtual_loss")
+
+    def set_eval_cache(self, entries):
+        """Opt-in: evaluation cache of `entries` positions in HBM (mcts.py:17,22 TODO), 0 = off; results are bit-identical."""
+        self._check(lib().az_set_eval_cache(self.h, C.c_int64(int(entries))), "az_set_eval_cache")
 
     def set_profiling(self, on):
         lib().az_set_profiling(self.h, 1 if on else 0)

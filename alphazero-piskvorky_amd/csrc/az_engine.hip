@@ -43,9 +43,10 @@ struct PackedNet {
 struct Lane {
     int index = 0;
     hipStream_t stream = nullptr;
-    DevState d{};
-    DevBuf board, s_game, s_ply, s_player, s_last, s_status, s_net, edges, rows_used, path, depth, leaf_kind, leaf,
-        leaf_last, logits, vhid, pol_feat, cnt, active_dev, carried, dbg, scratch;
+    DevState d{};                  // the games' view (B = slots of this lane)
+    DevState dv{};                 // the net kernels' view (B = evaluation items = slots x leaves per batch)
+    DevBuf board, s_game, s_ply, s_player, s_last, s_status, s_net, edges, rows_used, cnt, active_dev, carried;   // per slot
+    DevBuf path, depth, leaf_kind, leaf, leaf_last, logits, vhid, pol_feat, dbg, scratch, it_status, it_net;       // per evaluation item
     // one ply (k_begin, (S+1) x {trunk, fc, step}, k_move) captured once as a hipGraph and replayed every ply:
     // 3(S+1)+2 launches (6(S+1)+2 with the split trunk) become one submission.  Indexed [split trunk][arena].
     struct PlyGraph {
@@ -77,6 +78,10 @@ struct az_engine {
     int64_t tape_len = 0;          // doubles per game in the noise tape
     bool have_episode = false;
     int reuse = 0;
+    int vl = 1;                    // leaves per game and evaluation batch (az_set_virtual_loss); 1 = the reference's sequential loop
+    bool vl_kernel = false;        // the batched tree kernel is in use (vl > 1, or AZ_VL_FORCE=1 to run it with batches of one)
+    DevBuf cache;                  // evaluation cache shared by the lanes (az_set_eval_cache)
+    unsigned cache_mask = 0, cache_gen = 1;
     std::vector<int> h_nply, h_result;
     PackedNet net[2];
     az_counters last{};
@@ -105,6 +110,7 @@ static LaunchCtx ctx_of_impl(const az_engine *e, const Lane &L)
     LaunchCtx c{};
     c.stream = L.stream;
     c.d = L.d;
+    c.dv = L.dv;
     for (int i = 0; i < 2; i++) { c.w[i] = e->net[i].w; c.rw[i] = e->net[i].rw; }
     c.model = e->cfg.model;
     c.synthetic = e->cfg.eval_kind == AZ_EVAL_SYNTHETIC;
@@ -390,7 +396,41 @@ static int auto_lanes(int n, int slots)
 template <class F>
 static void each_state(az_engine *e, F f)
 {
-    for (Lane &L : e->lanes) f(L.d);
+    for (Lane &L : e->lanes) {
+        f(L.d);
+        L.dv = L.d;                                  // the net kernels see evaluation items instead of slots
+        L.dv.B = L.d.B * L.d.L;
+        L.dv.s_status = L.d.it_status;
+        L.dv.s_net = L.d.it_net;
+    }
+}
+
+// (re)allocates the per-item buffers of a lane for `leaves` leaves per game and batch
+static int alloc_items(az_engine *e, Lane &L, int leaves)
+{
+    const size_t NI = (size_t)L.d.B * leaves;
+    int rc = AZ_OK;
+#define ALLOC(buf, bytes) if (!rc) rc = dev_alloc(e, L.buf, (bytes))
+    ALLOC(path, (NI * (size_t)e->PATH + 64) * 4);   // +64: k_step's speculative path[lane] read of the last slot
+    ALLOC(depth, NI * 4);
+    ALLOC(leaf_kind, NI * 4); ALLOC(leaf, NI * 8 * sizeof(u64)); ALLOC(leaf_last, NI * 4);
+    ALLOC(logits, NI * (size_t)e->RW * 4); ALLOC(vhid, NI * 64 * 4);
+    ALLOC(pol_feat, NI * (size_t)((((e->cfg.model == AZ_MODEL_RESNET ? 3 : 6) * e->nn + 3) / 4) * 4) * 4);   // feature rows [NI][FROW], zero tail stays zero
+#ifdef AZ_STAMPS
+    ALLOC(dbg, (NI * 16 + 4096 * 32) * sizeof(unsigned long long));
+#endif
+    if (e->split_max > 0)    // zeroed once: the padding ring of the packed images is never written afterwards
+        ALLOC(scratch, (size_t)e->ops->split_scratch_floats((int)NI) * sizeof(float));
+    if (leaves > 1) { ALLOC(it_status, NI * 4); ALLOC(it_net, NI * 4); }
+#undef ALLOC
+    if (rc) return rc;
+    DevState &d = L.d;
+    d.L = leaves;
+    d.path = (unsigned *)L.path.p; d.depth = (int *)L.depth.p; d.leaf_kind = (int *)L.leaf_kind.p; d.leaf = (u64 *)L.leaf.p;
+    d.leaf_last = (int *)L.leaf_last.p; d.logits = (float *)L.logits.p; d.vhid = (float *)L.vhid.p;
+    d.it_status = leaves > 1 ? (int *)L.it_status.p : d.s_status;
+    d.it_net = leaves > 1 ? (int *)L.it_net.p : d.s_net;
+    return AZ_OK;
 }
 
 extern "C" int az_create(const az_config *cfg, az_engine **out)
@@ -457,18 +497,9 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
         ALLOC(s_game, B * 4); ALLOC(s_ply, B * 4); ALLOC(s_player, B * 4); ALLOC(s_last, B * 4);
         ALLOC(s_status, B * 4); ALLOC(s_net, B * 4);
         ALLOC(edges, B * (size_t)e->R * e->RW * sizeof(Edge));
-        ALLOC(rows_used, B * 4); ALLOC(depth, B * 4);
-        ALLOC(path, (B * (size_t)e->PATH + 64) * 4);   // +64: k_step's speculative path[lane] read of the last slot
-        ALLOC(leaf_kind, B * 4); ALLOC(leaf, B * 8 * sizeof(u64)); ALLOC(leaf_last, B * 4);
-        ALLOC(logits, B * (size_t)e->RW * 4); ALLOC(vhid, B * 64 * 4);
-        ALLOC(pol_feat, B * (size_t)((((cfg->model == AZ_MODEL_RESNET ? 3 : 6) * e->nn + 3) / 4) * 4) * 4);   // feature rows [B][FROW], zero tail stays zero
+        ALLOC(rows_used, B * 4);
         ALLOC(cnt, B * CNT_STRIDE * sizeof(unsigned long long)); ALLOC(active_dev, 16);
         ALLOC(carried, B * 4);
-#ifdef AZ_STAMPS
-        ALLOC(dbg, (B * 16 + 4096 * 32) * sizeof(unsigned long long));
-#endif
-        if (e->split_max > 0)    // zeroed once: the padding ring of the packed images is never written afterwards
-            ALLOC(scratch, (size_t)e->ops->split_scratch_floats((int)B) * sizeof(float));
 #undef ALLOC
         DevState &d = L.d;
         d.B = (int)B; d.R = e->R; d.S = cfg->num_simulations; d.k = cfg->win_length;
@@ -477,12 +508,12 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
         d.board = (u64 *)L.board.p;
         d.s_game = (int *)L.s_game.p; d.s_ply = (int *)L.s_ply.p; d.s_player = (int *)L.s_player.p;
         d.s_last = (int *)L.s_last.p; d.s_status = (int *)L.s_status.p; d.s_net = (int *)L.s_net.p;
-        d.edges = (Edge *)L.edges.p; d.rows_used = (int *)L.rows_used.p; d.path = (unsigned *)L.path.p;
-        d.depth = (int *)L.depth.p; d.leaf_kind = (int *)L.leaf_kind.p; d.leaf = (u64 *)L.leaf.p;
-        d.leaf_last = (int *)L.leaf_last.p; d.logits = (float *)L.logits.p; d.vhid = (float *)L.vhid.p;
+        d.edges = (Edge *)L.edges.p; d.rows_used = (int *)L.rows_used.p;
         d.cnt = (unsigned long long *)L.cnt.p; d.active = (int *)L.active_dev.p;
         d.carried = (int *)L.carried.p; d.reuse = 0;
         d.v2w[0] = d.v2w[1] = d.v2b[0] = d.v2b[1] = nullptr;
+        d.cache = nullptr; d.cache_mask = 0; d.cache_gen = e->cache_gen;
+        if (!rc) rc = alloc_items(e, L, 1);
     }
     if (!rc) rc = dev_alloc(e, e->next_game, 16);
     if (!rc) rc = dev_alloc(e, e->T_table, (size_t)(e->nn + 4) * sizeof(double));
@@ -536,7 +567,7 @@ extern "C" void az_destroy(az_engine *e)
     for (Lane &L : e->lanes) {
         DevBuf *all[] = {&L.board, &L.s_game, &L.s_ply, &L.s_player, &L.s_last, &L.s_status, &L.s_net, &L.edges, &L.rows_used,
                          &L.path, &L.depth, &L.leaf_kind, &L.leaf, &L.leaf_last, &L.logits, &L.vhid, &L.pol_feat, &L.cnt,
-                         &L.active_dev, &L.carried, &L.dbg, &L.scratch};
+                         &L.active_dev, &L.carried, &L.dbg, &L.scratch, &L.it_status, &L.it_net};
         for (DevBuf *b : all) dev_free(*b);
         for (hipEvent_t ev : L.ev) (void)hipEventDestroy(ev);
         for (int i = 0; i < 4; i++)
@@ -544,7 +575,7 @@ extern "C" void az_destroy(az_engine *e)
     }
     DevBuf *shared[] = {&e->T_table, &e->log_table, &e->sqrt_table, &e->noise_off, &e->next_game, &e->noise, &e->u,
                         &e->rec_planes, &e->rec_last, &e->rec_action, &e->rec_mover, &e->rec_pi, &e->rec_visits, &e->g_nply,
-                        &e->g_result, &e->src_index};
+                        &e->g_result, &e->src_index, &e->cache};
     for (DevBuf *b : shared) dev_free(*b);
     for (int s = 0; s < 2; s++) {
         PackedNet &p = e->net[s];
@@ -583,7 +614,8 @@ extern "C" int az_load_weights(az_engine *e, int slot, const float *const *t)
     p.w.hd = (const float *)p.hd.p; p.w.pf = (const float *)p.pf.p; p.w.vf = (const float *)p.vf.p;
     p.w.c1b = (const float *)p.c1b.p; p.w.c2b = (const float *)p.c2b.p; p.w.c3b = (const float *)p.c3b.p;
     p.w.hdb = (const float *)p.hdb.p; p.w.pfb = (const float *)p.pfb.p; p.w.vfb = (const float *)p.vfb.p;
-    each_state(e, [&](DevState &d) { d.v2w[slot] = (const float *)p.v2w.p; d.v2b[slot] = (const float *)p.v2b.p; });
+    e->cache_gen++;           // evaluations cached under the previous weights never match again
+    each_state(e, [&](DevState &d) { d.v2w[slot] = (const float *)p.v2w.p; d.v2b[slot] = (const float *)p.v2b.p; d.cache_gen = e->cache_gen; });
     p.loaded = true;
     return AZ_OK;
 }
@@ -615,7 +647,8 @@ extern "C" int az_load_weights_resnet(az_engine *e, int slot, const float *const
     p.w = NetWeights{};
     p.w.pf = (const float *)p.pf.p; p.w.vf = (const float *)p.vf.p;
     p.w.pfb = (const float *)p.pfb.p; p.w.vfb = (const float *)p.vfb.p;
-    each_state(e, [&](DevState &d) { d.v2w[slot] = (const float *)p.v2w.p; d.v2b[slot] = (const float *)p.v2b.p; });
+    e->cache_gen++;           // evaluations cached under the previous weights never match again
+    each_state(e, [&](DevState &d) { d.v2w[slot] = (const float *)p.v2w.p; d.v2b[slot] = (const float *)p.v2b.p; d.cache_gen = e->cache_gen; });
     p.loaded = true;
     return AZ_OK;
 }
@@ -689,6 +722,7 @@ static int episode_begin(az_engine *e, const EpisodeSpec &sp)
     each_state(e, [&](DevState &d) {
         d.max_plies = sp.max_plies; d.add_noise = sp.add_noise ? 1 : 0; d.arena = sp.arena ? 1 : 0;
         d.total_games = sp.num_games; d.reuse = e->reuse;
+        d.cache = (float *)e->cache.p; d.cache_mask = e->cache_mask; d.cache_gen = e->cache_gen;
     });
     az_engine::Run &r = e->run;
     r = az_engine::Run();
@@ -720,18 +754,35 @@ static int episode_begin(az_engine *e, const EpisodeSpec &sp)
     return AZ_OK;
 }
 
-// the kernel sequence of one ply: t = -1 consumes the root evaluation (root N = 0 for the first selection),
-// t >= 0 consumes simulation t
+// Evaluation batches of one ply: the root's evaluation, then the simulations -- one per batch in the reference's
+// sequential loop (mcts.py:123-141), `vl` per batch with virtual-loss batching.
+static int ply_batches(const az_engine *e) { return 1 + (e->vl_kernel ? (e->cfg.num_simulations + e->vl - 1) / e->vl : e->cfg.num_simulations); }
+
+// the tree kernel that consumes evaluation batch `idx` (0 = the root evaluation) and selects the leaves of batch idx + 1
+static void launch_step(const az_engine *e, const LaunchCtx &lc, int idx)
+{
+    const int S = lc.d.S;
+    if (e->vl_kernel) {
+        const int done = std::min(idx * e->vl, S);             // simulations finished once batch idx is consumed
+        e->ops->step_vl(lc, done, std::min(S - done, e->vl));
+    } else {
+        e->ops->step(lc, idx, idx < S ? 1 : 0);                // root N = idx for the next selection
+    }
+}
+
+// the kernel sequence of one ply
 static void launch_ply(az_engine *e, const LaunchCtx &lc, bool use_split, int nnets, bool net)
 {
     const DevState &d = lc.d;
     hipLaunchKernelGGL(k_begin, dim3((d.B + 255) / 256), dim3(256), 0, lc.stream, d);
-    for (int t = -1; t < d.S; t++) {
+    if (net && d.cache) e->ops->root_cache(lc);
+    const int nb = ply_batches(e);
+    for (int idx = 0; idx < nb; idx++) {
         if (net) {
             for (int id = 0; id < nnets; id++) { if (use_split) e->ops->trunk_split(lc, id); else e->ops->trunk(lc, id); }
             for (int id = 0; id < nnets; id++) e->ops->fc(lc, id);
         }
-        e->ops->step(lc, t + 1, (t + 1 < d.S) ? 1 : 0);
+        launch_step(e, lc, idx);
     }
     e->ops->move(lc);
 }
@@ -766,7 +817,8 @@ static int lane_plies(az_engine *e, Lane &L, int max_steps)
     const int S = d.S;
     const bool net = e->cfg.eval_kind == AZ_EVAL_NET;
     const bool prof = net && r.profile && e->profile;
-    const size_t need_ev = prof ? (size_t)4 * (S + 1) : 0;
+    const int nbat = ply_batches(e);
+    const size_t need_ev = prof ? (size_t)4 * nbat : 0;
     while (L.ev.size() < need_ev) {
         hipEvent_t ev;
         HIPCHECK_L(L, hipEventCreate(&ev));
@@ -778,7 +830,7 @@ static int lane_plies(az_engine *e, Lane &L, int max_steps)
     const char *skip = getenv("AZ_DIAG_SKIP");
     const bool skip_fc = skip && strstr(skip, "fc"), skip_step = skip && strstr(skip, "step");
     for (int step = 0; step < max_steps && L.active > 0; step++) {
-        const bool use_split = e->split_max > 0 && L.scratch.p && L.active <= e->split_max;   // few pending boards: latency path
+        const bool use_split = e->split_max > 0 && L.scratch.p && L.active * e->vl <= e->split_max;   // few pending boards: latency path
         if (e->tapes) {       // the tapes of this ply must be on the device (streamed a wave ahead of the games)
             hipEvent_t ev = nullptr;
             hipError_t trc = e->tapes->need(L.plies_played, &ev);
@@ -790,13 +842,14 @@ static int lane_plies(az_engine *e, Lane &L, int max_steps)
             int rcg = ply_graph(e, L, lc, use_split, nnets, net, &exec);
             if (rcg) return rcg;
             HIPCHECK_L(L, hipGraphLaunch(exec, L.stream));
-            if (net) L.trunk_launches += (int64_t)nnets * (S + 1);
-            L.steps += S + 1;
+            if (net) L.trunk_launches += (int64_t)nnets * nbat;
+            L.steps += nbat;
         } else {
             hipLaunchKernelGGL(k_begin, dim3((d.B + 255) / 256), dim3(256), 0, L.stream, d);
-            for (int t = -1; t < S; t++) {
+            if (net && d.cache) e->ops->root_cache(lc);
+            for (int idx = 0; idx < nbat; idx++) {
                 if (net) {
-                    const int ei = 4 * (t + 1);
+                    const int ei = 4 * idx;
                     if (prof) HIPCHECK_L(L, hipEventRecord(L.ev[ei], L.stream));
                     for (int id = 0; id < nnets; id++) { if (use_split) e->ops->trunk_split(lc, id); else e->ops->trunk(lc, id); }
                     if (prof) HIPCHECK_L(L, hipEventRecord(L.ev[ei + 1], L.stream));
@@ -804,9 +857,8 @@ static int lane_plies(az_engine *e, Lane &L, int max_steps)
                     if (prof) HIPCHECK_L(L, hipEventRecord(L.ev[ei + 2], L.stream));
                     L.trunk_launches += nnets;
                 }
-                // t = -1 consumes the root evaluation (root N = 0 for the first selection); t >= 0 consumes simulation t
-                if (!skip_step || t < 0) e->ops->step(lc, t + 1, (t + 1 < S) ? 1 : 0);
-                if (prof) HIPCHECK_L(L, hipEventRecord(L.ev[4 * (t + 1) + 3], L.stream));
+                if (!skip_step || idx == 0) launch_step(e, lc, idx);
+                if (prof) HIPCHECK_L(L, hipEventRecord(L.ev[4 * idx + 3], L.stream));
                 L.steps++;
             }
             e->ops->move(lc);
@@ -825,7 +877,7 @@ static int lane_plies(az_engine *e, Lane &L, int max_steps)
         HIPCHECK_L(L, hipGetLastError());
         L.plies_played++;
         if (prof) {
-            for (int i = 0; i <= S; i++) {
+            for (int i = 0; i < nbat; i++) {
                 float a = 0.f, b = 0.f, c = 0.f;
                 HIPCHECK_L(L, hipEventElapsedTime(&a, L.ev[4 * i], L.ev[4 * i + 1]));
                 HIPCHECK_L(L, hipEventElapsedTime(&b, L.ev[4 * i + 1], L.ev[4 * i + 2]));
@@ -881,6 +933,7 @@ static int read_counters(az_engine *e, az_counters &c)
 {
     c.expansions = c.simulations = c.terminal_hits = c.depth_sum = 0;
     c.steps = c.trunk_launches = c.plies = 0;
+    c.duplicate_leaves = c.cache_lookups = c.cache_hits = 0;
     int64_t reused = 0;
     double trunk_ms = 0.0, nn_ms = 0.0, step_ms = 0.0;
     for (Lane &L : e->lanes) {
@@ -892,6 +945,9 @@ static int read_counters(az_engine *e, az_counters &c)
             c.terminal_hits += (int64_t)hc[(size_t)b * CNT_STRIDE + 2];
             c.depth_sum += (int64_t)hc[(size_t)b * CNT_STRIDE + 3];
             reused += (int64_t)hc[(size_t)b * CNT_STRIDE + 4];
+            c.duplicate_leaves += (int64_t)hc[(size_t)b * CNT_STRIDE + 5];
+            c.cache_lookups += (int64_t)hc[(size_t)b * CNT_STRIDE + 6];
+            c.cache_hits += (int64_t)hc[(size_t)b * CNT_STRIDE + 7];
         }
         c.steps += L.steps; c.trunk_launches += L.trunk_launches; c.plies += L.plies;
         trunk_ms += L.trunk_ms; nn_ms += L.nn_ms; step_ms += L.step_ms;
@@ -902,7 +958,7 @@ static int read_counters(az_engine *e, az_counters &c)
     c.step_seconds = step_ms * 1e-3;
     c.root_evals = c.plies - reused;      // a retained root (subtree reuse) is not evaluated again
     c.records = c.plies;
-    c.trunk_boards = c.expansions + c.root_evals;
+    c.trunk_boards = c.expansions + c.root_evals - c.cache_hits;     // evaluations the net kernels actually ran
     c.games = e->run.num_games;
     return AZ_OK;
 }
@@ -935,7 +991,7 @@ static int episode_end(az_engine *e, az_counters *out)
     for (int g = 0; g < r.num_games; g++) plies += e->h_nply[g];
     r.c.plies = r.c.records = plies;
     r.c.root_evals = plies - r.reused_roots;
-    r.c.trunk_boards = r.c.expansions + r.c.root_evals;
+    r.c.trunk_boards = r.c.expansions + r.c.root_evals - r.c.cache_hits;
     e->last = r.c;
     e->episode_games = r.num_games;
     e->have_episode = true;
@@ -1149,7 +1205,7 @@ extern "C" int az_net_eval(az_engine *e, int slot, int count, const uint8_t *boa
     if (e->run.open) return fail(e, AZ_ERR_STATE, "az_net_eval: a self-play episode is open on this engine");
     DEVICE_GUARD(e);
     Lane &L = e->lanes[0];            // single-position and batch evaluation calls use lane 0
-    const int nn = e->nn, B = L.d.B;
+    const int nn = e->nn, B = L.dv.B;              // boards per pass = evaluation items of the lane
     DevBuf dpol, dval;
     int rc = dev_alloc(e, dpol, (size_t)B * nn * 4);
     if (!rc) rc = dev_alloc(e, dval, (size_t)B * 4);
@@ -1166,8 +1222,8 @@ extern "C" int az_net_eval(az_engine *e, int slot, int count, const uint8_t *boa
         }
         hipError_t hr = az_memcpy(e->stream, L.leaf.p, lf.data(), lf.size() * 8, hipMemcpyHostToDevice);
         if (hr == hipSuccess) hr = az_memcpy(e->stream, L.leaf_kind.p, kind.data(), (size_t)B * 4, hipMemcpyHostToDevice);
-        if (hr == hipSuccess) hr = az_memcpy(e->stream, L.s_status.p, st.data(), (size_t)B * 4, hipMemcpyHostToDevice);
-        if (hr == hipSuccess) hr = az_memcpy(e->stream, L.s_net.p, nets.data(), (size_t)B * 4, hipMemcpyHostToDevice);
+        if (hr == hipSuccess) hr = az_memcpy(e->stream, L.dv.s_status, st.data(), (size_t)B * 4, hipMemcpyHostToDevice);
+        if (hr == hipSuccess) hr = az_memcpy(e->stream, L.dv.s_net, nets.data(), (size_t)B * 4, hipMemcpyHostToDevice);
         if (hr == hipSuccess) hr = az_memcpy(e->stream, L.leaf_last.p, ll.data(), (size_t)B * 4, hipMemcpyHostToDevice);
         if (hr != hipSuccess) { rc = fail(e, AZ_ERR_HIP, "az_net_eval upload: %s", hipGetErrorString(hr)); break; }
         {
@@ -1185,7 +1241,7 @@ extern "C" int az_net_eval(az_engine *e, int slot, int count, const uint8_t *boa
         if (hr != hipSuccess) { rc = fail(e, AZ_ERR_HIP, "az_net_eval: %s", hipGetErrorString(hr)); break; }
     }
     // leave the slots idle
-    (void)hipMemsetAsync(L.s_status.p, 0, L.s_status.bytes, e->stream);
+    (void)hipMemsetAsync(L.dv.s_status, 0, (size_t)B * 4, e->stream);
     (void)hipMemsetAsync(L.leaf_kind.p, 0, L.leaf_kind.bytes, e->stream);
     (void)hipStreamSynchronize(e->stream);
     dev_free(dpol);
@@ -1362,6 +1418,7 @@ extern "C" int az_set_subtree_reuse(az_engine *e, int on)
 {
     if (!e) return AZ_ERR_INVALID;
     if (e->run.open) return fail(e, AZ_ERR_STATE, "az_set_subtree_reuse: an episode is open");
+    if (on && e->vl > 1) return fail(e, AZ_ERR_INVALID, "subtree reuse and virtual-loss batching cannot be combined");
     if (on && e->R > REUSE_MAX_ROWS)
         return fail(e, AZ_ERR_INVALID, "subtree reuse supports at most %d simulations per move", REUSE_MAX_ROWS - 1);
     e->reuse = on ? 1 : 0;
@@ -1383,3 +1440,50 @@ extern "C" int az_get_counters(const az_engine *e, az_counters *out)
 }
 
 extern "C" int az_get_lanes(const az_engine *e) { return e ? (int)e->lanes.size() : AZ_ERR_INVALID; }
+
+extern "C" int az_set_virtual_loss(az_engine *e, int leaves)
+{
+    if (!e) return AZ_ERR_INVALID;
+    if (e->run.open) return fail(e, AZ_ERR_STATE, "az_set_virtual_loss: an episode is open");
+    if (leaves < 1 || leaves > VL_MAX) return fail(e, AZ_ERR_INVALID, "virtual-loss batching supports 1..%d leaves per batch", VL_MAX);
+    if (leaves > 1 && e->reuse) return fail(e, AZ_ERR_INVALID, "subtree reuse and virtual-loss batching cannot be combined");
+    DEVICE_GUARD(e);
+    if (leaves != e->vl) {
+        for (Lane &L : e->lanes) {
+            int rc = alloc_items(e, L, leaves);
+            if (rc) return rc;
+            for (int i = 0; i < 4; i++)       // the captured plies bake the old buffers in
+                if (L.graph[i >> 1][i & 1].exec) { (void)hipGraphExecDestroy(L.graph[i >> 1][i & 1].exec); L.graph[i >> 1][i & 1].exec = nullptr; }
+        }
+        HIPCHECK(e, hipStreamSynchronize(e->stream));
+    }
+    e->vl = leaves;
+    const char *f = getenv("AZ_VL_FORCE");       // AZ_VL_FORCE=1: the batched kernel also for batches of one (must equal k_step)
+    e->vl_kernel = leaves > 1 || (f && f[0] == '1');
+    each_state(e, [&](DevState &d) { (void)d; });        // refresh the item views
+    return AZ_OK;
+}
+
+extern "C" int az_set_eval_cache(az_engine *e, int64_t entries)
+{
+    if (!e) return AZ_ERR_INVALID;
+    if (e->run.open) return fail(e, AZ_ERR_STATE, "az_set_eval_cache: an episode is open");
+    if (entries < 0 || entries > ((int64_t)1 << 26)) return fail(e, AZ_ERR_INVALID, "cache entries must be 0 (off) .. 2^26");
+    DEVICE_GUARD(e);
+    if (entries == 0) {
+        dev_free(e->cache);
+        e->cache_mask = 0;
+    } else {
+        int64_t n = 1024;
+        while (n < entries) n <<= 1;
+        const size_t ces = (size_t)(32 + e->RW + 64) * sizeof(float);       // CacheGeo<n>::CES floats per entry
+        dev_free(e->cache);
+        int rc = dev_alloc(e, e->cache, (size_t)n * ces, true);
+        if (rc) return rc;
+        HIPCHECK(e, hipStreamSynchronize(e->stream));
+        e->cache_mask = (unsigned)(n - 1);
+    }
+    e->cache_gen++;
+    each_state(e, [&](DevState &d) { d.cache = (float *)e->cache.p; d.cache_mask = e->cache_mask; d.cache_gen = e->cache_gen; });
+    return AZ_OK;
+}

@@ -5,7 +5,9 @@
 
 struct LaunchCtx {
     hipStream_t stream;
-    DevState d;
+    DevState d;         // the games' view: B = game slots
+    DevState dv;        // the net kernels' view: B = evaluation items (slots x leaves per batch), s_status / s_net per item;
+                        // identical to d unless virtual-loss batching is on
     NetWeights w[2];
     ResWeights rw[2];
     int model;          // AZ_MODEL_PLAIN | AZ_MODEL_RESNET
@@ -21,6 +23,8 @@ struct SizeOps {
     long long (*split_scratch_floats)(int slots);
     void (*fc)(const LaunchCtx &, int net_id);
     void (*step)(const LaunchCtx &, int rootN, int do_select);
+    void (*step_vl)(const LaunchCtx &, int sims_done, int nb_next);      // virtual-loss batching (DevState.L leaves per game)
+    void (*root_cache)(const LaunchCtx &);                                // evaluation-cache lookup of the root positions
     void (*move)(const LaunchCtx &);
     void (*eval_tail)(const LaunchCtx &, int count, float *policy, float *value);
 };

@@ -808,10 +808,12 @@ __global__ __launch_bounds__(G::FCW * 64) void k_fc(DevState d, NetWeights w, in
         }
     }
     FC_STAMP(2);
+    // only slots with a pending evaluation are written: the row of a slot whose evaluation came from the cache (or that
+    // waits on a terminal leaf) must stay as it is
 #pragma unroll
     for (int rg = 0; rg < 4; rg++) {
         int b = mb + q * 4 + rg;
-        if (b < d.B && d.s_net[b] == net_id) {
+        if (b < d.B && d.s_net[b] == net_id && leaf_needs_net(d.leaf_kind[b]) && d.s_status[b] == SLOT_ACTIVE) {
             if (is_pol) {
                 int j = tile * 16 + r16;
                 if (j < G::nn) d.logits[(size_t)b * G::RW + j] = acc[rg] + w.pfb[j];

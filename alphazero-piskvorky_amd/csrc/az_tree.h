@@ -10,9 +10,15 @@
 #include "az_device.h"
 
 enum { LEAF_NONE = 0, LEAF_EXPAND = 1, LEAF_TERM_LOSS = 2, LEAF_TERM_DRAW = 3, LEAF_ROOT = 4,
-       LEAF_REUSE = 5 };      // root retained from the previous ply's search (subtree reuse): no evaluation, noise mix only
+       LEAF_REUSE = 5,        // root retained from the previous ply's search (subtree reuse): no evaluation, noise mix only
+       LEAF_EXPAND_HIT = 6, LEAF_ROOT_HIT = 7,   // evaluation cache hit: logits / hidden row already in place, the net kernels skip the slot
+       LEAF_DUP_BASE = 16 };  // virtual-loss batching: LEAF_DUP_BASE + i = same leaf as item i of this batch (no second evaluation)
+__host__ __device__ constexpr bool leaf_needs_net(int kind) { return kind == LEAF_ROOT || kind == LEAF_EXPAND; }
+constexpr int VL_MAX = 32;             // leaves per batch in virtual-loss mode (5 spare bits of the edge's visit field)
+constexpr int EDGE_N_BITS = 11, EDGE_N_MASK = (1 << EDGE_N_BITS) - 1;   // visit count 0..1024 in the low bits, in-flight count above
 constexpr int REUSE_MAX_ROWS = 1024;   // rows per slot (S + 2) the in-place compaction of k_move can renumber
-constexpr int CNT_STRIDE = 8;  // per-slot counters: expansions, simulations, terminal hits, depth sum, reused roots
+constexpr int CNT_STRIDE = 8;  // per-slot counters: expansions, simulations, terminal hits, depth sum, reused roots, duplicate leaves,
+                               // cache lookups, cache hits
 enum { SLOT_IDLE = 0, SLOT_ACTIVE = 1, SLOT_FINISHED = 2 };
 
 struct __attribute__((aligned(16))) Edge {
@@ -65,6 +71,13 @@ struct DevState {
     int *carried;          // [B] visits the retained root already holds (sum of its children's N), -1 = fresh root
     int *next_game;        // device counter
     int *active;           // number of active slots after refill
+    // --- opt-in evaluation cache (the reference's TODO, mcts.py:17 DEFAULT_CACHE_SIZE, mcts.py:22 "add caching") ---
+    float *cache;          // [cache_mask + 1][CACHE_HDR + RW + 64] floats, nullptr = off; shared by the lanes of an engine
+    unsigned cache_mask;   // entries - 1 (a power of two)
+    unsigned cache_gen;    // bumped by every weight load: entries of older weights never match
+    // --- opt-in virtual-loss batching (the reference's TODO, mcts.py:17-22): L leaves per game and evaluation batch ---
+    int L;                 // 1 = the reference's sequential simulation loop (mcts.py:123-141)
+    int *it_status, *it_net;   // [B*L] per evaluation item, what the net kernels read as s_status / s_net (alias them when L == 1)
 };
 
 template <int N>
@@ -79,6 +92,104 @@ __device__ __forceinline__ void wave_mem_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Evaluation cache (opt-in; the reference only names it: mcts.py:17 DEFAULT_CACHE_SIZE = 500_000, mcts.py:22 "TODO: add
+// caching").  Key = what the net sees: mover planes, opponent planes, last move (games.py:86-129 encode) + which net +
+// the weights generation.  Value = the net's raw outputs for that input, policy logits and value-head hidden row, i.e.
+// exactly the floats the trunk + FC kernels would produce again, so a hit changes nothing downstream (visit counts are
+// bit-identical with the cache on or off).  Direct-mapped table in HBM shared by every lane of the engine; entries are
+// written and read by whole wavefronts with plain loads/stores and carry a checksum bound to the key: an entry torn by
+// a concurrent writer (another lane's kernel) fails the check and counts as a miss.
+//   entry = [9 x u64 key][u64 checksum][pad to 128 B][RW logits][64 hidden]
+// ------------------------------------------------------------------------------------------------
+constexpr int CACHE_HDR = 32;      // floats
+template <int N>
+struct CacheGeo {
+    static constexpr int CES = CACHE_HDR + TreeGeo<N>::RW + 64;     // floats per entry
+};
+__device__ __forceinline__ u64 cache_mix(u64 h, u64 v)
+{
+    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    h *= 0xFF51AFD7ED558CCDull;
+    h ^= h >> 33;
+    return h;
+}
+__device__ __forceinline__ u64 cache_key8(int last, int net, unsigned gen)
+{
+    return (u64)(unsigned)(last + 1) | ((u64)(unsigned)net << 16) | ((u64)gen << 32);
+}
+__device__ __forceinline__ u64 cache_hash(const Plane &me, const Plane &opp, u64 k8)
+{
+    u64 h = 0x243F6A8885A308D3ull;
+#pragma unroll
+    for (int q = 0; q < 4; q++) h = cache_mix(h, me.w[q]);
+#pragma unroll
+    for (int q = 0; q < 4; q++) h = cache_mix(h, opp.w[q]);
+    return cache_mix(h, k8);
+}
+// the key word lane `lane` (0..8) is responsible for
+__device__ __forceinline__ u64 cache_keyword(const Plane &me, const Plane &opp, u64 k8, int lane)
+{
+    u64 w = k8;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        w = lane == q ? me.w[q] : w;
+        w = lane == 4 + q ? opp.w[q] : w;
+    }
+    return w;
+}
+template <int CPL>
+__device__ __forceinline__ u64 cache_checksum(const float (&x)[CPL], float h, int lane, u64 hsh)
+{
+    unsigned a = 0u, b = 0u;
+#pragma unroll
+    for (int i = 0; i <= CPL; i++) {
+        const unsigned w = __float_as_uint(i < CPL ? x[i < CPL ? i : 0] : h);
+        const unsigned pos = (unsigned)(lane + 64 * i);
+        a ^= az_fmix32(w + pos * 0x9E3779B1u);
+        b ^= az_fmix32((w ^ 0xA5A5A5A5u) + pos * 0x85EBCA77u + 0x5BD1E995u);
+    }
+    a = wave_xor_u(a);
+    b = wave_xor_u(b);
+    return ((((u64)a) << 32) | (u64)b) ^ hsh;
+}
+// wave-uniform call: true = the entry of (me, opp, last, net) was found intact; its rows are then in x / h
+template <int N>
+__device__ __forceinline__ bool cache_lookup(const DevState &d, const Plane &me, const Plane &opp, int last, int net, int lane,
+                                             float (&x)[TreeGeo<N>::CPL], float &h)
+{
+    typedef TreeGeo<N> G;
+    const u64 k8 = cache_key8(last, net, d.cache_gen);
+    const u64 hsh = cache_hash(me, opp, k8);
+    const float *ent = d.cache + (size_t)((unsigned)hsh & d.cache_mask) * CacheGeo<N>::CES;
+    const u64 *kp = reinterpret_cast<const u64 *>(ent);
+    const u64 mine = cache_keyword(me, opp, k8, lane);
+    const u64 got = lane < 10 ? kp[lane] : 0ull;
+#pragma unroll
+    for (int i = 0; i < G::CPL; i++) x[i] = ent[CACHE_HDR + lane + 64 * i];
+    h = ent[CACHE_HDR + G::RW + lane];
+    const bool key_ok = __ballot(lane < 9 && got != mine) == 0ull;
+    const u64 cs = cache_checksum<G::CPL>(x, h, lane, hsh);
+    const u64 stored = (u64)__shfl((long long)got, 9, 64);
+    return key_ok && cs == stored;
+}
+template <int N>
+__device__ __forceinline__ void cache_insert(const DevState &d, const Plane &me, const Plane &opp, int last, int net, int lane,
+                                             const float (&x)[TreeGeo<N>::CPL], float h)
+{
+    typedef TreeGeo<N> G;
+    const u64 k8 = cache_key8(last, net, d.cache_gen);
+    const u64 hsh = cache_hash(me, opp, k8);
+    float *ent = d.cache + (size_t)((unsigned)hsh & d.cache_mask) * CacheGeo<N>::CES;
+    u64 *kp = reinterpret_cast<u64 *>(ent);
+    const u64 cs = cache_checksum<G::CPL>(x, h, lane, hsh);
+    const u64 mine = lane == 9 ? cs : cache_keyword(me, opp, k8, lane);
+    if (lane < 10) kp[lane] = mine;
+#pragma unroll
+    for (int i = 0; i < G::CPL; i++) ent[CACHE_HDR + lane + 64 * i] = x[i];
+    ent[CACHE_HDR + G::RW + lane] = h;
+}
 
 // controller.py:49 softmax over all n^2 logits (no legality mask) in the canonical wave order, and the
 // value tail value_fc2 + tanh (net.py:70) as one k-ordered fma chain.  P[i] is the prior of cell lane+64*i.
@@ -142,18 +253,30 @@ __global__ void k_begin(DevState d)
 {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= d.B) return;
-    if (d.s_status[b] != SLOT_ACTIVE) { d.leaf_kind[b] = LEAF_NONE; return; }
+    const int L = d.L;
+    const size_t it = (size_t)b * L;                     // evaluation items of this game: the root is item 0
+    if (d.s_status[b] != SLOT_ACTIVE) {
+        for (int j = 0; j < L; j++) {
+            d.leaf_kind[it + j] = LEAF_NONE;
+            if (L > 1) d.it_status[it + j] = SLOT_IDLE;
+        }
+        return;
+    }
     int pl = d.s_player[b];
     const u64 *bd = d.board + (size_t)b * 8;
-    u64 *lf = d.leaf + (size_t)b * 8;
+    u64 *lf = d.leaf + it * 8;
     for (int i = 0; i < 4; i++) {
         lf[i] = pl == 1 ? bd[i] : bd[4 + i];
         lf[4 + i] = pl == 1 ? bd[4 + i] : bd[i];
     }
-    d.leaf_last[b] = d.s_last[b];
-    d.leaf_kind[b] = (d.reuse && d.carried[b] >= 0) ? LEAF_REUSE : LEAF_ROOT;
-    d.depth[b] = 0;
-    d.s_net[b] = d.arena ? (pl == 1 ? 0 : 1) : 0;   // evaluator.py:73-79: each side searches with its own net
+    d.leaf_last[it] = d.s_last[b];
+    d.leaf_kind[it] = (d.reuse && d.carried[b] >= 0) ? LEAF_REUSE : LEAF_ROOT;
+    d.depth[it] = 0;
+    const int netid = d.arena ? (pl == 1 ? 0 : 1) : 0;   // evaluator.py:73-79: each side searches with its own net
+    d.s_net[b] = netid;
+    for (int j = 1; j < L; j++) d.leaf_kind[it + j] = LEAF_NONE;
+    if (L > 1)
+        for (int j = 0; j < L; j++) { d.it_status[it + j] = SLOT_ACTIVE; d.it_net[it + j] = netid; }
 }
 
 #endif  // AZ_ENGINE_TU
@@ -177,7 +300,9 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
 
     // ---- independent loads, all in flight together ----
     const int status = d.s_status[bb];
-    const int kind = d.leaf_kind[bb];
+    const int kind_raw = d.leaf_kind[bb];
+    // a cache hit (LEAF_*_HIT) is consumed exactly like the evaluation it stands for; it is just not inserted again
+    const int kind = kind_raw == LEAF_EXPAND_HIT ? LEAF_EXPAND : (kind_raw == LEAF_ROOT_HIT ? LEAF_ROOT : kind_raw);
     const int depth0 = d.depth[bb];
     const int rows0 = d.rows_used[bb];
     const int pl = d.s_player[bb];
@@ -254,6 +379,12 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
                 int vv = (int)(az_fmix32(hs ^ 0x7F4A7C15u) & 0x1FFu);
                 v = (float)(vv - 256) / 256.0f;
             } else {
+                if (d.cache && kind_raw == kind) {            // a fresh evaluation: remember it
+                    float xc[G::CPL];
+#pragma unroll
+                    for (int i = 0; i < G::CPL; i++) xc[i] = lane + 64 * i < G::nn ? x[i] : 0.0f;
+                    cache_insert<N>(d, lme, lopp, leaf_last, netid, lane, xc, h_l);
+                }
                 // controller.py:49 softmax over all n^2 logits (no legality mask), canonical wave order
                 float mx = -INFINITY;
 #pragma unroll
@@ -375,12 +506,306 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
         npar = an;
         row = child;
     }
+    if (!SYNTH && d.cache && out_kind == LEAF_EXPAND) {
+        // the leaf's evaluation may be known already (an earlier ply's search, another game, a transposition)
+        float cx[G::CPL], ch;
+        const bool hit = cache_lookup<N>(d, me, opp, last, netid, lane, cx, ch);
+        if (hit) {
+#pragma unroll
+            for (int i = 0; i < G::CPL; i++) d.logits[(size_t)b * G::RW + lane + 64 * i] = cx[i];
+            d.vhid[(size_t)b * 64 + lane] = ch;
+            out_kind = LEAF_EXPAND_HIT;
+        }
+        if (lane == 0) {
+            d.cnt[(size_t)b * CNT_STRIDE + 6] += 1ull;
+            d.cnt[(size_t)b * CNT_STRIDE + 7] += hit ? 1ull : 0ull;
+        }
+    }
     if (lane == 0) {
         pl_store(d.leaf + (size_t)b * 8, me);
         pl_store(d.leaf + (size_t)b * 8 + 4, opp);
         d.leaf_last[b] = last;
         d.leaf_kind[b] = out_kind;
         d.depth[b] = depth;
+    }
+}
+
+// Evaluation cache for ROOT evaluations: runs after k_begin, one wave per slot.
+template <int N>
+__global__ __launch_bounds__(256) void k_root_cache(DevState d)
+{
+    typedef TreeGeo<N> G;
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= d.B || d.s_status[b] != SLOT_ACTIVE) return;
+    const size_t it = (size_t)b * d.L;                 // the root is item 0 of its game
+    if (d.leaf_kind[it] != LEAF_ROOT) return;
+    const Plane me = pl_load(d.leaf + it * 8), opp = pl_load(d.leaf + it * 8 + 4);
+    float cx[G::CPL], ch;
+    const bool hit = cache_lookup<N>(d, me, opp, d.leaf_last[it], d.s_net[b], lane, cx, ch);
+    if (hit) {
+#pragma unroll
+        for (int i = 0; i < G::CPL; i++) d.logits[it * G::RW + lane + 64 * i] = cx[i];
+        d.vhid[it * 64 + lane] = ch;
+    }
+    if (lane == 0) {
+        if (hit) d.leaf_kind[it] = LEAF_ROOT_HIT;
+        d.cnt[(size_t)b * CNT_STRIDE + 6] += 1ull;
+        d.cnt[(size_t)b * CNT_STRIDE + 7] += hit ? 1ull : 0ull;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_step_vl: the tree step with virtual-loss batching (opt-in; the reference's loop mcts.py:123-141 is strictly
+// sequential and only lists "virtual loss" as a TODO, mcts.py:17-22).  A game owns L evaluation items; every launch
+//   stage 1: finishes the simulations of the pending batch in selection order -- takes the in-flight visit back from the
+//            path, expands the leaf with its evaluation and backs the value up exactly like mcts.py:136-141; a
+//            "duplicate" (its leaf was already pending for an earlier item of the batch) backs up that item's value;
+//   stage 2: selects the next batch: item j descends with every edge on the paths of items 0..j-1 counting one extra
+//            visit that lost (N + 1, W - 1), and leaves its own in-flight mark on the edges it takes.
+// The in-flight count lives in the 5 spare bits of the edge's 16-bit visit field; W is never touched by it, so taking
+// a virtual visit back is exact.  Same arithmetic and operator order as the oracle's restatement (orc_cfg.vl); with
+// L = 1 it reproduces k_step.  Dynamic LDS: (S + 2) doubles.
+// ------------------------------------------------------------------------------------------------
+template <int N, bool SYNTH>
+__device__ __forceinline__ void vl_leaf_eval(const DevState &d, size_t it, const Plane &lme, const Plane &lopp, int leaf_last,
+                                             int netid, bool fresh, int lane, float (&P)[TreeGeo<N>::CPL], float &v)
+{
+    typedef TreeGeo<N> G;
+    if (SYNTH) {
+        unsigned hx = 0;
+#pragma unroll
+        for (int i = 0; i < G::CPL; i++) {
+            int j = lane + 64 * i;
+            if (j < G::nn) {
+                unsigned code = pl_get(lme, j) ? 1u : (pl_get(lopp, j) ? 2u : 0u);
+                hx ^= az_fmix32((unsigned)j * 3u + code + 0x9E3779B9u);
+            }
+        }
+        unsigned hs = wave_xor_u(hx);
+        hs ^= az_fmix32(0x51ED270Bu + (unsigned)(leaf_last + 1));
+#pragma unroll
+        for (int i = 0; i < G::CPL; i++) {
+            int j = lane + 64 * i;
+            unsigned r = az_fmix32(hs + (unsigned)(j + 1) * 0x9E3779B1u);
+            P[i] = (float)(((r >> 8) & 0xFFFFu) + 1u) * 0x1p-23f;
+        }
+        int vv = (int)(az_fmix32(hs ^ 0x7F4A7C15u) & 0x1FFu);
+        v = (float)(vv - 256) / 256.0f;
+        return;
+    }
+    float x[G::CPL];
+    const float *lg = d.logits + it * G::RW;
+#pragma unroll
+    for (int i = 0; i < G::CPL; i++) x[i] = lane + 64 * i < G::nn ? lg[lane + 64 * i] : 0.0f;
+    const float h_l = d.vhid[it * 64 + lane];
+    const float w2_l = d.v2w[netid][lane];
+    const float b2 = d.v2b[netid][0];
+    if (d.cache && fresh) cache_insert<N>(d, lme, lopp, leaf_last, netid, lane, x, h_l);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < G::CPL; i++) {
+        if (lane + 64 * i >= G::nn) x[i] = -INFINITY;
+        mx = fmaxf(mx, x[i]);
+    }
+    mx = wave_max_f(mx);
+    float part = 0.0f;
+#pragma unroll
+    for (int i = 0; i < G::CPL; i++) {
+        P[i] = 0.0f;
+        if (lane + 64 * i < G::nn) {
+            P[i] = az_expf(x[i] - mx);
+            part = part + P[i];
+        }
+    }
+    const float ssum = wave_sum_butterfly(part);
+#pragma unroll
+    for (int i = 0; i < G::CPL; i++) P[i] = P[i] / ssum;
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 64; i++) acc = __builtin_fmaf(__shfl(h_l, i, 64), __shfl(w2_l, i, 64), acc);
+    v = az_tanhf(acc + b2);
+}
+
+template <int N, bool SYNTH>
+__global__ __launch_bounds__(256) void k_step_vl(DevState d, int sims_done, int nb_next)
+{
+    typedef TreeGeo<N> G;
+    extern __shared__ double sq_lds[];                 // np.sqrt(N + 1e-8), N = 0..S+1 (mcts.py:73)
+    __shared__ float vals_lds[4][VL_MAX];              // leaf values of the batch being finished (duplicates read them)
+    __shared__ unsigned pend_lds[4][VL_MAX];           // leaf edge (row << 16 | cell) of every item waiting for an evaluation
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wv;
+    for (int i = threadIdx.x; i < d.S + 2; i += 256) sq_lds[i] = d.sqrt_table[i];
+    __syncthreads();
+    if (b >= d.B || d.s_status[b] != SLOT_ACTIVE) return;
+    const int L = d.L;
+    const size_t it0 = (size_t)b * L;
+    Edge *rows = d.edges + (size_t)b * d.R * G::RW;
+    const int pl = d.s_player[b], slast = d.s_last[b], netid = d.s_net[b], game = d.s_game[b], ply = d.s_ply[b];
+    const Plane bX = pl_load(d.board + (size_t)b * 8), bO = pl_load(d.board + (size_t)b * 8 + 4);
+    float *vals = vals_lds[wv];
+    unsigned *pend = pend_lds[wv];
+    int rows_used = d.rows_used[b];
+    unsigned long long c_exp = 0, c_sim = 0, c_term = 0, c_depth = 0, c_dup = 0, c_look = 0, c_hit = 0;
+
+    // ---------------- stage 1: finish the pending batch in selection order ----------------
+    for (int j = 0; j < L; j++) {
+        const size_t it = it0 + j;
+        const int kind_raw = d.leaf_kind[it];
+        if (kind_raw == LEAF_NONE) continue;
+        const int kind = kind_raw == LEAF_EXPAND_HIT ? LEAF_EXPAND : (kind_raw == LEAF_ROOT_HIT ? LEAF_ROOT : kind_raw);
+        const int depth0 = d.depth[it];
+        unsigned *path = d.path + it * G::PATH;
+        float v = 0.0f;
+        if (kind == LEAF_ROOT || kind == LEAF_EXPAND) {
+            const Plane lme = pl_load(d.leaf + it * 8), lopp = pl_load(d.leaf + it * 8 + 4);
+            const int leaf_last = d.leaf_last[it];
+            float P[G::CPL];
+            vl_leaf_eval<N, SYNTH>(d, it, lme, lopp, leaf_last, netid, kind_raw == kind, lane, P, v);
+            if (kind == LEAF_ROOT && d.add_noise) {
+                // mcts.py:113-116; float32 multiply, float64 add, float32 store
+                Plane occ;
+#pragma unroll
+                for (int q = 0; q < 4; q++) occ.w[q] = lme.w[q] | lopp.w[q];
+                const double *nz = d.noise + (size_t)game * d.noise_stride + d.noise_off[ply];
+#pragma unroll
+                for (int i = 0; i < G::CPL; i++) {
+                    int c = lane + 64 * i;
+                    if (c < G::nn && !pl_get(occ, c)) {
+                        int rank = c - pl_rank(occ, c);
+                        float scaled = d.one_minus_w * P[i];
+                        P[i] = (float)((double)scaled + d.w_noise * nz[rank]);
+                    }
+                }
+            }
+            // mcts.py:50-64 expand: one edge per cell (occupied cells are never selected)
+            const int row = kind == LEAF_ROOT ? 0 : rows_used;
+#pragma unroll
+            for (int i = 0; i < G::CPL; i++) {
+                Edge e;
+                e.W = 0.0; e.P = P[i]; e.N = 0; e.child = 0;
+                rows[(size_t)row * G::RW + lane + 64 * i] = e;
+            }
+            rows_used = row + 1;
+            if (kind == LEAF_EXPAND) {
+                const unsigned pe = path[depth0 - 1];
+                if (lane == 0) rows[(size_t)(pe >> 16) * G::RW + (pe & 0xFFFFu)].child = (unsigned short)row;
+            }
+        }
+        vals[j] = v;                                    // every lane holds the same v
+        if (kind != LEAF_ROOT) {
+            // mcts.py:132-134,141,76-82: value w.r.t. the side to move at the leaf, backed up with alternating sign
+            double value;
+            if (kind == LEAF_EXPAND) value = (double)v;
+            else if (kind >= LEAF_DUP_BASE) value = (double)vals[kind - LEAF_DUP_BASE];
+            else value = kind == LEAF_TERM_LOSS ? -1.0 : 0.0;
+            for (int dd = lane; dd < depth0; dd += 64) {
+                const unsigned pe = path[dd];
+                Edge *e = rows + (size_t)(pe >> 16) * G::RW + (pe & 0xFFFFu);
+                const double val = ((depth0 - 1 - dd) & 1) ? value : -value;
+                e->N = (unsigned short)(e->N - (1 << EDGE_N_BITS) + 1);      // the in-flight visit becomes a real one
+                e->W = e->W + val;
+            }
+            c_exp += kind == LEAF_EXPAND ? 1ull : 0ull;
+            c_dup += kind >= LEAF_DUP_BASE ? 1ull : 0ull;
+            c_term += (kind == LEAF_TERM_LOSS || kind == LEAF_TERM_DRAW) ? 1ull : 0ull;
+            c_sim += 1ull;
+            c_depth += (unsigned long long)depth0;
+        }
+        wave_mem_sync();
+    }
+
+    // ---------------- stage 2: select the next batch (mcts.py:124-129 with in-flight visits counted as losses) ----------------
+    const Plane rme = pl == 1 ? bX : bO, ropp = pl == 1 ? bO : bX;
+    for (int j = 0; j < L; j++) {
+        const size_t it = it0 + j;
+        if (j >= nb_next) {
+            if (lane == 0) d.leaf_kind[it] = LEAF_NONE;
+            continue;
+        }
+        Plane me = rme, opp = ropp;
+        int row = 0, npar = sims_done + j, depth = 0, last = slast, out_kind = LEAF_NONE;
+        unsigned *path = d.path + it * G::PATH;
+        unsigned leaf_edge = 0xFFFFFFFFu;
+        for (;;) {
+            Plane occ;
+#pragma unroll
+            for (int q = 0; q < 4; q++) occ.w[q] = me.w[q] | opp.w[q];
+            const double sq = sq_lds[npar];                       // np.sqrt(self.N + 1e-8), mcts.py:73
+            double best = 0.0;
+            int bi = -1, bN = 0, bC = 0;
+#pragma unroll
+            for (int i = 0; i < G::CPL; i++) {
+                int c = lane + 64 * i;
+                if (c < G::nn && !pl_get(occ, c)) {
+                    Edge e = rows[(size_t)row * G::RW + c];
+                    const int fl = (int)e.N >> EDGE_N_BITS;               // simulations of this batch in flight through the edge
+                    const int nv = ((int)e.N & EDGE_N_MASK) + fl;
+                    const double wvv = e.W - (double)fl;
+                    double Q = nv ? wvv / (double)nv : 0.0;
+                    double sc = Q + ((d.c_puct * (double)e.P) * sq) / (double)(1 + nv);
+                    if (bi < 0 || sc > best) { best = sc; bi = c; bN = nv; bC = e.child; }
+                }
+            }
+            wave_argmax(best, bi);
+            const int a = __builtin_amdgcn_readfirstlane(bi);
+            if (a < 0) { out_kind = LEAF_NONE; break; }
+            const int child = __shfl(bC, a & 63, 64);
+            const int an = __shfl(bN, a & 63, 64);
+            if (lane == (a & 63)) {
+                Edge *e = rows + (size_t)row * G::RW + a;
+                e->N = (unsigned short)(e->N + (1 << EDGE_N_BITS));
+            }
+            if (lane == 0) path[depth] = ((unsigned)row << 16) | (unsigned)a;
+            leaf_edge = ((unsigned)row << 16) | (unsigned)a;
+            depth++;
+            pl_set(me, a);                                        // games.py:79-81 place, flip player, remember action
+            Plane t = me; me = opp; opp = t;
+            last = a;
+            if (wins_through(opp, a, N, d.k)) { out_kind = LEAF_TERM_LOSS; break; }
+            if (pl_count(me) + pl_count(opp) == G::nn) { out_kind = LEAF_TERM_DRAW; break; }
+            if (child == 0) { out_kind = LEAF_EXPAND; break; }    // mcts.py:127 node.is_leaf()
+            npar = an;
+            row = child;
+        }
+        unsigned mark = 0xFFFFFFFFu;
+        if (out_kind == LEAF_EXPAND) {
+            int dup = -1;
+            for (int i = 0; i < j; i++)
+                if (dup < 0 && pend[i] == leaf_edge) dup = i;
+            if (dup >= 0) {
+                out_kind = LEAF_DUP_BASE + dup;
+            } else {
+                mark = leaf_edge;
+                if (!SYNTH && d.cache) {
+                    float cx[G::CPL], ch;
+                    const bool hit = cache_lookup<N>(d, me, opp, last, netid, lane, cx, ch);
+                    if (hit) {
+#pragma unroll
+                        for (int i = 0; i < G::CPL; i++) d.logits[it * G::RW + lane + 64 * i] = cx[i];
+                        d.vhid[it * 64 + lane] = ch;
+                        out_kind = LEAF_EXPAND_HIT;
+                    }
+                    c_look += 1ull;
+                    c_hit += hit ? 1ull : 0ull;
+                }
+            }
+        }
+        pend[j] = mark;
+        if (lane == 0) {
+            pl_store(d.leaf + it * 8, me);
+            pl_store(d.leaf + it * 8 + 4, opp);
+            d.leaf_last[it] = last;
+            d.leaf_kind[it] = out_kind;
+            d.depth[it] = depth;
+        }
+        wave_mem_sync();
+    }
+    if (lane == 0) {
+        d.rows_used[b] = rows_used;
+        unsigned long long *c = d.cnt + (size_t)b * CNT_STRIDE;
+        c[0] += c_exp; c[1] += c_sim; c[2] += c_term; c[3] += c_depth; c[5] += c_dup; c[6] += c_look; c[7] += c_hit;
     }
 }
 
@@ -437,7 +862,7 @@ __global__ __launch_bounds__(256) void k_move(DevState d)
     for (int i = 0; i < G::CPL; i++) {
         int j = lane + 64 * i;
         legal[i] = j < G::nn && !pl_get(occ, j);
-        Nj[i] = legal[i] ? (int)root[j].N : 0;
+        Nj[i] = legal[i] ? (int)root[j].N & EDGE_N_MASK : 0;
         rank[i] = legal[i] ? j - pl_rank(occ, j) : 0;
     }
     bool uniform = false;
@@ -547,7 +972,7 @@ __global__ __launch_bounds__(256) void k_move(DevState d)
             d.g_nply[g] = ply + 1;
             d.s_status[b] = SLOT_FINISHED;
         }
-        d.leaf_kind[b] = LEAF_NONE;
+        d.leaf_kind[(size_t)b * d.L] = LEAF_NONE;
     }
     if (!d.reuse) return;
     // ---- subtree reuse: the chosen child's subtree becomes the next ply's tree ----
@@ -653,7 +1078,7 @@ __global__ __launch_bounds__(1024) void k_refill(DevState d, int claim_cap)
                 d.s_player[b] = (d.arena && (gid & 1)) ? 2 : 1;   // evaluator.py:64-69
                 d.s_last[b] = -1;
                 d.s_status[b] = SLOT_ACTIVE;
-                d.leaf_kind[b] = LEAF_NONE;
+                d.leaf_kind[(size_t)b * d.L] = LEAF_NONE;
                 d.carried[b] = -1;
                 newact = 1;
             } else {
@@ -707,7 +1132,7 @@ __global__ void k_set_position(DevState d, int slot, int game, int player, int l
     d.s_player[slot] = player;
     d.s_last[slot] = last;
     d.s_status[slot] = SLOT_ACTIVE;
-    d.leaf_kind[slot] = LEAF_NONE;
+    d.leaf_kind[(size_t)slot * d.L] = LEAF_NONE;
     d.carried[slot] = -1;
 }
 #endif  // AZ_ENGINE_TU

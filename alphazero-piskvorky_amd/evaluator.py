@@ -17,11 +17,13 @@ def temperature_schedule(move: int) -> float:
 
 
 class ModelEvaluator:
-    def __init__(self, game_class=None, print_games=False, device=None, seed=None):
+    def __init__(self, game_class=None, print_games=False, device=None, seed=None, virtual_loss=1, eval_cache=0):
         self.game_class = game_class
         self.print_games = print_games
         self.device = device if device is not None else torch.device("cuda")
         self.seed = seed
+        self.virtual_loss = virtual_loss      # opt-in search upgrades (mcts.py:17-22 TODO), see include/az_engine.h
+        self.eval_cache = eval_cache
         self._engine = None
 
     def evaluate(self, candidate_controller, baseline_controller, num_games=20, debug=False):
@@ -35,12 +37,14 @@ class ModelEvaluator:
         lo, hi = parallel.arena_block(num_games, rank, world)
         mine = hi - lo
         dev = torch.device("cuda", device_index(self.device))
-        key = (n, k, S, max(mine, 1), model_kind(candidate_controller.net))
+        key = (n, k, S, max(mine, 1), model_kind(candidate_controller.net), self.virtual_loss, self.eval_cache)
         if self._engine is None or self._key != key:
             if self._engine is not None:
                 self._engine.close()
             self._engine = Engine(n, k, S, max(1, min(mine, _c.CONCURRENT_GAMES)), c_puct=_c.EVAL_EXPLORATION_CONSTANT,
                                   device=device_index(self.device), log_table=numpy_log_table(S), model=key[4])
+            self._engine.set_virtual_loss(self.virtual_loss)
+            self._engine.set_eval_cache(self.eval_cache)
             self._key = key
         eng = self._engine
         eng.load_weights(candidate_controller.net.state_dict(), 0)

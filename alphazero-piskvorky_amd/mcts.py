@@ -17,7 +17,7 @@ def numpy_log_table(S):
 
 
 class MCTS:
-    def __init__(self, policy_value_fn, num_simulations, c_puct, dirichlet_alpha=0.3, dirichlet_weight=0.25):
+    def __init__(self, policy_value_fn, num_simulations, c_puct, dirichlet_alpha=0.3, dirichlet_weight=0.25, virtual_loss=1):
         if not isinstance(policy_value_fn, PolicyValueFn):
             raise NotImplementedError(
                 "the GPU search evaluates leaves inside the HIP engine; pass make_policy_value_fn(controller) "
@@ -27,6 +27,7 @@ class MCTS:
         self.c_puct = c_puct
         self.dirichlet_alpha = dirichlet_alpha
         self.dirichlet_weight = dirichlet_weight
+        self.virtual_loss = virtual_loss      # opt-in: leaves per evaluation batch (az_set_virtual_loss); 1 = the reference's loop
         self._engine = None
         self._version = None
 
@@ -37,6 +38,7 @@ class MCTS:
                                   dirichlet_alpha=self.dirichlet_alpha, dirichlet_weight=self.dirichlet_weight,
                                   device=device_index(ctrl.device), log_table=numpy_log_table(self.num_simulations),
                                   model=model_kind(ctrl.net))
+            self._engine.set_virtual_loss(self.virtual_loss)
             self._version = None
         ver = weights_version(ctrl.net)
         if ver != self._version:

@@ -21,7 +21,8 @@ class SelfPlayManager:
     def __init__(self, controller, device, mcts_params: dict = None,
                  temperature_schedule: Callable[[int], float] = default_temperature_schedule,
                  concurrent_games: int = None, augmentation: int = AZ_AUG_REFERENCE4, seed: int = None,
-                 engines_per_gpu: int = None, subtree_reuse: bool = False, gather_to: int = None):
+                 engines_per_gpu: int = None, subtree_reuse: bool = False, gather_to: int = None,
+                 eval_cache: int = 0, virtual_loss: int = 1):
         self.controller = controller
         self.device = device
         self.mcts_params = mcts_params or {"num_simulations": 100}
@@ -31,6 +32,8 @@ class SelfPlayManager:
         self.seed = seed
         self.engines_per_gpu = engines_per_gpu      # None: az_config.engines = 0, the library chooses
         self.subtree_reuse = subtree_reuse    # opt-in search upgrade (mcts.py:17-22 TODO); off = the reference's fresh root every move
+        self.eval_cache = eval_cache          # opt-in: positions kept in the device evaluation cache (mcts.py:17,22 TODO); results unchanged
+        self.virtual_loss = virtual_loss      # opt-in: leaves per search and evaluation batch (mcts.py:17-22 TODO); 1 = sequential like the reference
         self.gather_to = gather_to            # multi-rank: None = every rank receives all records (all-gather); r = only rank r does
         self.last_counters = None
         self._engine = None
@@ -38,7 +41,8 @@ class SelfPlayManager:
     def _eng(self, n, k, slots):
         p = self.mcts_params
         key = (n, k, p.get("num_simulations", 100), slots, p.get("c_puct", _c.SELF_PLAY_EXPLORATION_CONSTANT),
-               p.get("dirichlet_alpha", 0.3), p.get("dirichlet_weight", 0.25), model_kind(self.controller.net))
+               p.get("dirichlet_alpha", 0.3), p.get("dirichlet_weight", 0.25), model_kind(self.controller.net),
+               self.virtual_loss, self.eval_cache)
         if self._engine is None or self._engine_key != key:
             if self._engine is not None:
                 self._engine.close()
@@ -46,6 +50,8 @@ class SelfPlayManager:
             self._engine = Engine(n, k, key[2], slots, engines=self.engines_per_gpu or 0, c_puct=key[4], dirichlet_alpha=key[5],
                                   dirichlet_weight=key[6], device=device_index(self.device),
                                   log_table=numpy_log_table(key[2]), model=key[7])
+            self._engine.set_virtual_loss(self.virtual_loss)
+            self._engine.set_eval_cache(self.eval_cache)
             self._engine_key = key
         return self._engine
 

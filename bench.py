@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--model", default="plain", choices=["plain", "resnet"], help="plain = GomokuNet (net.py); resnet = ResidualBlock variant (config 5)")
     ap.add_argument("--no-episode", action="store_true", help="skip playing the episode to its end")
     ap.add_argument("--subtree-reuse", action="store_true", help="opt-in search upgrade (not the reference's algorithm): keep the chosen child's subtree between plies")
+    ap.add_argument("--eval-cache", type=int, default=0, help="opt-in search upgrade (results unchanged): device evaluation cache with this many entries")
+    ap.add_argument("--virtual-loss", type=int, default=1, help="opt-in search upgrade (not the reference's algorithm): leaves per search and evaluation batch")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--pmc-run", action="store_true", help="counter-collection run: 8 sims per move so the pass stays short")
     a = ap.parse_args()
@@ -127,6 +129,10 @@ def main():
     eng.load_weights(sd, 0)
     if a.subtree_reuse:
         eng.set_subtree_reuse(True)
+    if a.virtual_loss > 1:
+        eng.set_virtual_loss(a.virtual_loss)
+    if a.eval_cache > 0:
+        eng.set_eval_cache(a.eval_cache)
     # every rank plays its own shard of the episode's games: ids rank*B .. rank*B+B-1 (seed = seed0 + id)
     eng.selfplay_begin(B, seed0=1_000_000 + rank * B)
 
@@ -260,11 +266,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "collectives": (td.get_backend() if dist else None),
             "config": {"workload": f"{n}x{n} / {k}-in-a-row self-play, {B} concurrent games per GPU, {S} sims/move "
-                                   f"{'(BASELINE.json configs[3] per-GPU shard)' if (n, k, S, B, a.model) == (15, 5, 400, 1024, 'plain') else '(custom)'}, {'GomokuNet' if a.model == 'plain' else 'ResidualBlock net'} random-init weights, numpy-compatible RNG tapes{', SUBTREE REUSE ON (not the reference algorithm)' if a.subtree_reuse else ''}",
+                                   f"{'(BASELINE.json configs[3] per-GPU shard)' if (n, k, S, B, a.model) == (15, 5, 400, 1024, 'plain') else '(custom)'}, {'GomokuNet' if a.model == 'plain' else 'ResidualBlock net'} random-init weights, numpy-compatible RNG tapes{', SUBTREE REUSE ON (not the reference algorithm)' if a.subtree_reuse else ''}{f', VIRTUAL-LOSS BATCHES OF {a.virtual_loss} (not the reference algorithm)' if a.virtual_loss > 1 else ''}{f', evaluation cache of {a.eval_cache} entries (results unchanged)' if a.eval_cache else ''}",
                        "board": n, "win_length": k, "sims_per_move": S, "games_per_gpu": B, "engines_per_gpu": a.engines, "parallelism": f"games sharded x{world}" + (" (ranks sharing GPUs, gloo rehearsal)" if share else "")},
             "per_gpu_node_expansions_per_sec": exp_all / dt / world,
             "simulations_per_sec": sims_all / dt, "plies_per_sec": plies_all / dt,
             "mean_select_depth": depth_all / max(sims_all, 1), "terminal_hit_fraction": term_all / max(sims_all, 1),
+            "eval_cache_hit_rate": (d["cache_hits"] / d["cache_lookups"]) if d.get("cache_lookups") else None,
             "self_play_games_per_sec": None if episode is None else episode["games_per_sec"],
             "self_play_games_per_sec_steady_state": None if episode is None or "steady_state" not in episode else episode["steady_state"]["games_per_sec"],
             "episode": episode,

@@ -140,6 +140,8 @@ typedef struct {
     int64_t trunk_launches;
     int64_t trunk_boards;               /* boards evaluated by the trunk kernel (all launches)           */
     double step_seconds;                /* HIP-event time inside the tree kernel k_step (select/expand/backup) */
+    int64_t duplicate_leaves;           /* virtual-loss batching: simulations that met a leaf already pending in their batch */
+    int64_t cache_lookups, cache_hits;  /* evaluation cache: positions looked up / found (a hit skips the net kernels)  */
 } az_counters;
 
 int az_selfplay(az_engine *e, const az_selfplay_args *args, az_counters *out);
@@ -221,6 +223,30 @@ int az_rng_uniforms(uint64_t seed, int count, double *u);
  * unpinned" by the reference).  Self-play only; arena games and az_search always start from a fresh root.  Needs
  * num_simulations <= 1023.  Not allowed while an episode is open. */
 int az_set_subtree_reuse(az_engine *e, int on);
+
+/* Opt-in: virtual-loss batching within a search, the third item of the reference's TODO list (mcts.py:17-22); its
+ * simulation loop (mcts.py:123-141) is strictly sequential: select one leaf, evaluate it, back it up.  With `leaves` = L > 1
+ * the num_simulations simulations of a search run in batches of L: the leaves of a batch are selected one after another
+ * from the same tree, each selection counting the earlier ones of its batch as one visit that lost on every edge of their
+ * paths (N + 1, W - 1 in mcts.py:73's formula), then the L leaves are evaluated together, and the simulations are
+ * finished in selection order exactly like mcts.py:136-141 (the virtual visit is taken back first).  A selection that
+ * ends on a leaf an earlier one of its batch is waiting on does not evaluate again: it backs up that leaf's value
+ * (az_counters.duplicate_leaves).  Every search still makes exactly num_simulations simulations, in
+ * ceil(num_simulations / L) dependent evaluation batches instead of num_simulations -- the lever for the latency-bound
+ * uses (az_search, az_arena, episode tails).  Visit counts differ from the reference's sequential search, so parity is
+ * against the oracle's restatement of this rule ("parity unpinned" by the reference); L = 1 is the reference's loop.
+ * 1 <= leaves <= 32.  Not combinable with subtree reuse; not allowed while an episode is open. */
+int az_set_virtual_loss(az_engine *e, int leaves);
+
+/* Opt-in: evaluation cache, the first item of the reference's TODO list (mcts.py:17 DEFAULT_CACHE_SIZE = 500_000,
+ * mcts.py:22 "TODO: add caching").  A table in HBM keyed on what the net sees -- mover planes, opponent planes, last
+ * move (games.py:86-129), which weight slot -- holding the net's raw outputs (policy logits, value-head hidden row).
+ * A leaf or root whose position is in the table skips the conv trunk and the FC layers; the values are the very floats
+ * those kernels would produce again, so visit counts, pi and moves are bit-identical with the cache on or off.
+ * Shared by all lanes of the engine and kept across plies, games and episodes; every az_load_weights* call invalidates
+ * it.  entries = 0 switches it off (and frees it); otherwise rounded up to a power of two, (96 + roundup(n*n, 64)) * 4
+ * bytes each.  Hits are reported in az_counters.cache_lookups / cache_hits.  Not allowed while an episode is open. */
+int az_set_eval_cache(az_engine *e, int64_t entries);
 
 /* HIP-event timing of every trunk / FC / tree-step launch (az_counters.trunk_seconds, nn_seconds, step_seconds);
  * off by default: four events per evaluation batch cost a few microseconds of stream time, which matters on small boards.
