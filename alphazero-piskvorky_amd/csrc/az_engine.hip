@@ -80,6 +80,8 @@ struct az_engine {
     int reuse = 0;
     int vl = 1;                    // leaves per game and evaluation batch (az_set_virtual_loss); 1 = the reference's sequential loop
     bool vl_kernel = false;        // the batched tree kernel is in use (vl > 1, or AZ_VL_FORCE=1 to run it with batches of one)
+    bool persist_allowed = true;   // AZ_PERSIST=0: never use the persistent search kernel
+    int persist_gp = 0;            // games per workgroup of the persistent search kernel for the open episode, 0 = lock-step pipeline
     DevBuf cache;                  // evaluation cache shared by the lanes (az_set_eval_cache)
     unsigned cache_mask = 0, cache_gen = 1;
     std::vector<int> h_nply, h_result;
@@ -114,6 +116,8 @@ static LaunchCtx ctx_of_impl(const az_engine *e, const Lane &L)
     for (int i = 0; i < 2; i++) { c.w[i] = e->net[i].w; c.rw[i] = e->net[i].rw; }
     c.model = e->cfg.model;
     c.synthetic = e->cfg.eval_kind == AZ_EVAL_SYNTHETIC;
+    c.persist_gp = e->persist_gp;
+    c.vl_kernel = e->vl_kernel ? 1 : 0;
     c.feat = (float *)L.pol_feat.p;
     c.dbg = (unsigned long long *)L.dbg.p;
     c.scratch = (float *)L.scratch.p;
@@ -534,6 +538,8 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
     }
     const char *pe = getenv("AZ_PROFILE_EVENTS");
     e->profile = pe && pe[0] == '1';
+    const char *pz = getenv("AZ_PERSIST");
+    e->persist_allowed = !(pz && pz[0] == '0');
     const char *ge = getenv("AZ_GRAPH");
     e->use_graph = !(ge && ge[0] == '0');
     const char *ts = getenv("AZ_TAPE_STREAM");
@@ -724,6 +730,14 @@ static int episode_begin(az_engine *e, const EpisodeSpec &sp)
         d.total_games = sp.num_games; d.reuse = e->reuse;
         d.cache = (float *)e->cache.p; d.cache_mask = e->cache_mask; d.cache_gen = e->cache_gen;
     });
+    // persistent search kernel: plain net or synthetic evaluator, the reference's sequential search, trees that fit into LDS
+    e->persist_gp = 0;
+    if (e->persist_allowed && e->cfg.model == AZ_MODEL_PLAIN && !e->vl_kernel && !e->reuse && !e->cache.p) {
+        const int synth = e->cfg.eval_kind == AZ_EVAL_SYNTHETIC ? 1 : 0;
+        const int S = e->cfg.num_simulations;
+        if (!sp.arena && !sp.preset && e->ops->search_prepare(S, 2, synth)) e->persist_gp = 2;
+        else if (e->ops->search_prepare(S, 1, synth)) e->persist_gp = 1;     // arena: a workgroup's games must share one net
+    }
     az_engine::Run &r = e->run;
     r = az_engine::Run();
     r.num_games = sp.num_games; r.max_plies = sp.max_plies; r.add_noise = sp.add_noise; r.arena = sp.arena;
@@ -775,6 +789,11 @@ static void launch_ply(az_engine *e, const LaunchCtx &lc, bool use_split, int nn
 {
     const DevState &d = lc.d;
     hipLaunchKernelGGL(k_begin, dim3((d.B + 255) / 256), dim3(256), 0, lc.stream, d);
+    if (e->persist_gp) {               // small boards: the whole search of the ply in one persistent kernel (az_search.h)
+        e->ops->search(lc, e->persist_gp);
+        e->ops->move(lc);
+        return;
+    }
     if (net && d.cache) e->ops->root_cache(lc);
     const int nb = ply_batches(e);
     for (int idx = 0; idx < nb; idx++) {
@@ -842,12 +861,25 @@ static int lane_plies(az_engine *e, Lane &L, int max_steps)
             int rcg = ply_graph(e, L, lc, use_split, nnets, net, &exec);
             if (rcg) return rcg;
             HIPCHECK_L(L, hipGraphLaunch(exec, L.stream));
-            if (net) L.trunk_launches += (int64_t)nnets * nbat;
+            if (net) L.trunk_launches += e->persist_gp ? 1 : (int64_t)nnets * nbat;
             L.steps += nbat;
         } else {
             hipLaunchKernelGGL(k_begin, dim3((d.B + 255) / 256), dim3(256), 0, L.stream, d);
-            if (net && d.cache) e->ops->root_cache(lc);
-            for (int idx = 0; idx < nbat; idx++) {
+            if (net && d.cache && !e->persist_gp) e->ops->root_cache(lc);
+            if (e->persist_gp) {
+                // one launch does the whole search; the events time it as a whole (it contains the conv trunk, the FC
+                // layers and the tree steps of S + 1 evaluation batches)
+                if (prof) HIPCHECK_L(L, hipEventRecord(L.ev[0], L.stream));
+                e->ops->search(lc, e->persist_gp);
+                if (prof) {
+                    HIPCHECK_L(L, hipEventRecord(L.ev[1], L.stream));
+                    HIPCHECK_L(L, hipEventRecord(L.ev[2], L.stream));
+                    HIPCHECK_L(L, hipEventRecord(L.ev[3], L.stream));
+                }
+                if (net) L.trunk_launches += 1;
+                L.steps += nbat;
+            }
+            for (int idx = 0; idx < nbat && !e->persist_gp; idx++) {
                 if (net) {
                     const int ei = 4 * idx;
                     if (prof) HIPCHECK_L(L, hipEventRecord(L.ev[ei], L.stream));
@@ -877,7 +909,7 @@ static int lane_plies(az_engine *e, Lane &L, int max_steps)
         HIPCHECK_L(L, hipGetLastError());
         L.plies_played++;
         if (prof) {
-            for (int i = 0; i < nbat; i++) {
+            for (int i = 0; i < (e->persist_gp ? 1 : nbat); i++) {
                 float a = 0.f, b = 0.f, c = 0.f;
                 HIPCHECK_L(L, hipEventElapsedTime(&a, L.ev[4 * i], L.ev[4 * i + 1]));
                 HIPCHECK_L(L, hipEventElapsedTime(&b, L.ev[4 * i + 1], L.ev[4 * i + 2]));
@@ -1287,9 +1319,10 @@ extern "C" int az_search(az_engine *e, int slot, const uint8_t *board, int playe
     // the arena flag only selects the net through s_player; a search with the baseline net uses slot 1 weights as slot 0
     PackedNet saved0 = e->net[0];
     const float *sv2w = L0.d.v2w[0], *sv2b = L0.d.v2b[0];
-    if (slot == 1) { e->net[0] = e->net[1]; L0.d.v2w[0] = L0.d.v2w[1]; L0.d.v2b[0] = L0.d.v2b[1]; }
+    // (the evaluation cache keys its entries by net id: the swapped search runs under its own cache generation)
+    if (slot == 1) { e->net[0] = e->net[1]; L0.d.v2w[0] = L0.d.v2w[1]; L0.d.v2b[0] = L0.d.v2b[1]; e->cache_gen ^= 0x80000000u; }
     rc = run_episode(e, sp, nullptr);
-    if (slot == 1) { e->net[0] = saved0; L0.d.v2w[0] = sv2w; L0.d.v2b[0] = sv2b; }
+    if (slot == 1) { e->net[0] = saved0; L0.d.v2w[0] = sv2w; L0.d.v2b[0] = sv2b; e->cache_gen ^= 0x80000000u; }
     if (rc) return rc;
     // outputs: record 0*nn + stones
     const size_t ri = (size_t)stones;

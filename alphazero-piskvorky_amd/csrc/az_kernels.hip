@@ -82,6 +82,49 @@ void root_cache(const LaunchCtx &c)
     hipLaunchKernelGGL(k_root_cache<N>, g, b, 0, c.stream, c.d);
 }
 
+constexpr bool HAS_SEARCH = N <= 7;      // the LDS-resident tree needs (S + 1) * n*n * 16 B per game
+
+template <int GP, bool SY>
+int search_prepare_t(int S)
+{
+    if constexpr (HAS_SEARCH) {
+        const void *fn = reinterpret_cast<const void *>(&k_search<N, GP, SY>);
+        hipFuncAttributes at;
+        if (hipFuncGetAttributes(&at, fn) != hipSuccess) return 0;
+        const size_t dyn = (size_t)GP * (S + 1) * N * N * sizeof(Edge);
+        if (at.sharedSizeBytes + dyn > 160u * 1024u) return 0;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return 0;
+        return 1;
+    } else {
+        return 0;
+    }
+}
+
+int search_prepare(int S, int games, int synthetic)
+{
+    if (games == 2) return synthetic ? search_prepare_t<2, true>(S) : search_prepare_t<2, false>(S);
+    if (games == 1) return synthetic ? search_prepare_t<1, true>(S) : search_prepare_t<1, false>(S);
+    return 0;
+}
+
+template <int GP>
+void search_t(const LaunchCtx &c)
+{
+    if constexpr (HAS_SEARCH) {
+        dim3 g((c.d.B + GP - 1) / GP), b(AZ_NW * 64);
+        const size_t dyn = (size_t)GP * c.d.R * N * N * sizeof(Edge);
+        if (c.synthetic)
+            hipLaunchKernelGGL((k_search<N, GP, true>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1]);
+        else
+            hipLaunchKernelGGL((k_search<N, GP, false>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1]);
+    }
+}
+
+void search(const LaunchCtx &c, int games)
+{
+    if (games == 2) search_t<2>(c); else search_t<1>(c);
+}
+
 void move(const LaunchCtx &c)
 {
     dim3 g((c.d.B + 3) / 4), b(256);
@@ -97,6 +140,6 @@ void eval_tail_l(const LaunchCtx &c, int count, float *pol, float *val)
 
 const SizeOps *AZ_CAT(az_size_ops_, AZ_N)()
 {
-    static const SizeOps ops = {trunk, trunk_split, split_scratch_floats, fc, step, step_vl, root_cache, move, eval_tail_l};
+    static const SizeOps ops = {trunk, trunk_split, split_scratch_floats, fc, step, step_vl, root_cache, search_prepare, search, move, eval_tail_l};
     return &ops;
 }

@@ -2,6 +2,7 @@
 // (az_kernels.hip compiled with -DAZ_N=n, in parallel); the engine dispatches through this table.
 #pragma once
 #include "az_net.h"
+#include "az_search.h"
 
 struct LaunchCtx {
     hipStream_t stream;
@@ -12,6 +13,8 @@ struct LaunchCtx {
     ResWeights rw[2];
     int model;          // AZ_MODEL_PLAIN | AZ_MODEL_RESNET
     int synthetic;      // AZ_EVAL_SYNTHETIC
+    int persist_gp;     // games per workgroup of the persistent search kernel, 0 = lock-step pipeline (part of the graph key)
+    int vl_kernel;      // the batched (virtual-loss) tree kernel is in use (part of the graph key)
     float *feat;
     unsigned long long *dbg;
     float *scratch;     // split-trunk images, SizeOps::split_floats_per_group floats per board group (or null)
@@ -25,6 +28,10 @@ struct SizeOps {
     void (*step)(const LaunchCtx &, int rootN, int do_select);
     void (*step_vl)(const LaunchCtx &, int sims_done, int nb_next);      // virtual-loss batching (DevState.L leaves per game)
     void (*root_cache)(const LaunchCtx &);                                // evaluation-cache lookup of the root positions
+    // persistent search kernel (az_search.h): prepare returns 1 when `games` games per workgroup with S simulations fit
+    // into LDS on the current device (and raises the kernel's dynamic-LDS limit), 0 when this size has no such kernel
+    int (*search_prepare)(int S, int games, int synthetic);
+    void (*search)(const LaunchCtx &, int games);
     void (*move)(const LaunchCtx &);
     void (*eval_tail)(const LaunchCtx &, int count, float *policy, float *value);
 };

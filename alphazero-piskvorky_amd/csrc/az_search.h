@@ -1,0 +1,370 @@
+// az_search.h -- persistent per-workgroup search kernel for small boards: the whole MCTS.run of a ply (mcts.py:101-141)
+// in ONE launch, with the tree of every game resident in LDS.
+//
+// The lock-step pipeline (az_engine.hip launch_ply) spends three dependent dispatches per simulation -- k_trunk, k_fc,
+// k_step -- and on small boards the ~5 us between dependent dispatches is a third of a simulation's time.  Here a
+// workgroup of 8 waves owns GP games for a whole ply and loops S + 1 times over
+//     encode -> conv1 -> conv2 -> conv3 -> 1x1 heads        (all 8 waves, MFMA, activations in LDS like k_trunk)
+//     policy_fc / value_fc1                                  (one k-ordered fmaf chain per output and thread)
+//     softmax + value tail, expand, backup, PUCT select      (one wavefront per game, like k_step)
+// without leaving the CU: the node array -- one row of n*n 16-byte edges per expanded node, (S + 1) rows per game --
+// lives in LDS next to the activations, so a level of the descent is one ds_read_b128 per lane instead of an L2 round
+// trip, and nothing but the weights (L2 hits), the root's Dirichlet noise and the final root row crosses the CU boundary.
+// Same fma chains and the same operator order as the three kernels it replaces: results are bit-identical (every
+// parity test runs on both paths).  Used when the rows fit: GP * (S + 1) * n*n * 16 B beside the activation image,
+// i.e. boards up to 7x7 at the reference's simulation counts (5x5: two games per workgroup at S = 100).
+#pragma once
+#include "az_net.h"
+
+template <int N, int GP>
+struct PersistGeo {
+    static constexpr int n = N, nn = N * N, PW = N + 2, PP = PW * PW;
+    static constexpr int G = GP;                                   // games (boards) per workgroup
+    static constexpr int M = G * nn;
+    static constexpr bool ROWT = false;
+    static constexpr int MT = (M + 15) / 16, MR = MT * 16;
+    static constexpr int CS = up16(G * PP);
+    static constexpr int CS3 = up16(MR);
+    static constexpr int LDSF = (96 * CS > 128 * CS3) ? 96 * CS : 128 * CS3;
+    static constexpr int RW = ((nn + 63) / 64) * 64;
+    static constexpr int NW = AZ_NW;
+    static constexpr int PC = 4, VC = 2;
+    static constexpr int FROW = (((PC + VC) * nn + 3) / 4) * 4;
+    static constexpr int PATH = nn + 1;
+    static constexpr int ROWE = nn;                                // edges per tree row in LDS (no padding to 64)
+    // static LDS of the kernel besides the tree rows (bytes), for the host's fit test
+    static constexpr int STATIC_BYTES = LDSF * 4 + MR * 4 + G * (FROW + RW + 64) * 4 + G * (PATH * 4 + 64 + 32) + 1024 * 8 + 64 + 256;
+};
+
+// LDS-resident search state of one game
+struct GameLds {
+    u64 leaf[8];           // mover-relative planes of the pending leaf
+    int leaf_last, leaf_kind, depth, rows_used;
+};
+
+// the tree step of one game on LDS rows: k_step's two stages (az_tree.h) with the node array, the path and the evaluator
+// outputs in LDS.  One wavefront.  No subtree reuse, no evaluation cache on this path.
+template <int N, class PG, bool SYNTH>
+__device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edge *rows, unsigned *path, GameLds &gs,
+                                         const float *lg, const float *hid, const double *sq_lds, int rootN, int do_select,
+                                         int pl, int slast, int netid, int game, int ply, const Plane &bX, const Plane &bO,
+                                         unsigned long long (&cnt)[4])
+{
+    typedef TreeGeo<N> G;
+    static_assert(G::CPL == 1, "the LDS tree is for boards of at most 64 cells");
+    const int kind = gs.leaf_kind, depth0 = gs.depth, rows0 = gs.rows_used, leaf_last = gs.leaf_last;
+    Plane lme, lopp;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { lme.w[q] = gs.leaf[q]; lopp.w[q] = gs.leaf[4 + q]; }
+    // ---------------- stage 1: evaluation -> expand -> backup ----------------
+    if (kind != LEAF_NONE) {
+        float v = 0.0f;
+        if (kind == LEAF_ROOT || kind == LEAF_EXPAND) {
+            float P;
+            if (SYNTH) {
+                unsigned hx = 0;
+                if (lane < G::nn) {
+                    unsigned code = pl_get(lme, lane) ? 1u : (pl_get(lopp, lane) ? 2u : 0u);
+                    hx = az_fmix32((unsigned)lane * 3u + code + 0x9E3779B9u);
+                }
+                unsigned hs = wave_xor_u(hx);
+                hs ^= az_fmix32(0x51ED270Bu + (unsigned)(leaf_last + 1));
+                unsigned r = az_fmix32(hs + (unsigned)(lane + 1) * 0x9E3779B1u);
+                P = (float)(((r >> 8) & 0xFFFFu) + 1u) * 0x1p-23f;
+                int vv = (int)(az_fmix32(hs ^ 0x7F4A7C15u) & 0x1FFu);
+                v = (float)(vv - 256) / 256.0f;
+            } else {
+                // controller.py:49 softmax over all n^2 logits (no legality mask), canonical wave order
+                const float x = lane < G::nn ? lg[lane] : -INFINITY;
+                const float mx = wave_max_f(x);
+                P = 0.0f;
+                float part = 0.0f;
+                if (lane < G::nn) {
+                    P = az_expf(x - mx);
+                    part = part + P;
+                }
+                const float ssum = wave_sum_butterfly(part);
+                P = P / ssum;
+                // value tail: value_fc2 + tanh (net.py:70), one k-ordered fma chain
+                const float h_l = hid[lane], w2_l = d.v2w[netid][lane];
+                float acc = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 64; i++) acc = __builtin_fmaf(__shfl(h_l, i, 64), __shfl(w2_l, i, 64), acc);
+                v = az_tanhf(acc + d.v2b[netid][0]);
+            }
+            if (kind == LEAF_ROOT && d.add_noise) {
+                // mcts.py:113-116; float32 multiply, float64 add, float32 store
+                Plane occ;
+#pragma unroll
+                for (int q = 0; q < 4; q++) occ.w[q] = lme.w[q] | lopp.w[q];
+                const double *nz = d.noise + (size_t)game * d.noise_stride + d.noise_off[ply];
+                if (lane < G::nn && !pl_get(occ, lane)) {
+                    int rank = lane - pl_rank(occ, lane);
+                    float scaled = d.one_minus_w * P;
+                    P = (float)((double)scaled + d.w_noise * nz[rank]);
+                }
+            }
+            // mcts.py:50-64 expand: one edge per cell (occupied cells are never selected)
+            const int row = kind == LEAF_ROOT ? 0 : rows0;
+            if (lane < PG::ROWE) {
+                Edge e;
+                e.W = 0.0; e.P = P; e.N = 0; e.child = 0;
+                rows[row * PG::ROWE + lane] = e;
+            }
+            if (lane == 0) gs.rows_used = row + 1;
+            if (kind == LEAF_EXPAND) {
+                const unsigned pe = path[depth0 - 1];
+                if (lane == 0) rows[(pe >> 16) * PG::ROWE + (pe & 0xFFFFu)].child = (unsigned short)row;
+            }
+        }
+        if (kind != LEAF_ROOT) {
+            // mcts.py:132-134,141,76-82: value w.r.t. the side to move at the leaf, backed up with alternating sign
+            const double value = kind == LEAF_EXPAND ? (double)v : (kind == LEAF_TERM_LOSS ? -1.0 : 0.0);
+            for (int dd = lane; dd < depth0; dd += 64) {
+                const unsigned pe = path[dd];
+                Edge *e = rows + (pe >> 16) * PG::ROWE + (pe & 0xFFFFu);
+                const double val = ((depth0 - 1 - dd) & 1) ? value : -value;
+                e->N = (unsigned short)(e->N + 1);
+                e->W = e->W + val;
+            }
+            cnt[0] += kind == LEAF_EXPAND ? 1ull : 0ull;
+            cnt[1] += 1ull;
+            cnt[2] += kind == LEAF_EXPAND ? 0ull : 1ull;
+            cnt[3] += (unsigned long long)depth0;
+        }
+        wave_mem_sync();
+    }
+    // ---------------- stage 2: selection (mcts.py:124-129) ----------------
+    if (!do_select) {
+        if (lane == 0) gs.leaf_kind = LEAF_NONE;
+        return;
+    }
+    Plane me = pl == 1 ? bX : bO;
+    Plane opp = pl == 1 ? bO : bX;
+    int row = 0, npar = rootN, depth = 0, last = slast, out_kind = LEAF_NONE;
+    for (;;) {
+        Plane occ;
+#pragma unroll
+        for (int q = 0; q < 4; q++) occ.w[q] = me.w[q] | opp.w[q];
+        const double sq = sq_lds[npar];                       // np.sqrt(self.N + 1e-8), mcts.py:73
+        double best = 0.0;
+        int bi = -1, bN = 0, bC = 0;
+        if (lane < G::nn && !pl_get(occ, lane)) {
+            Edge e = rows[row * PG::ROWE + lane];
+            double Q = e.N ? e.W / (double)e.N : 0.0;         // mcts.py:80 Q = W/N (0.0 while unvisited)
+            best = Q + ((d.c_puct * (double)e.P) * sq) / (double)(1 + (int)e.N);
+            bi = lane; bN = e.N; bC = e.child;
+        }
+        wave_argmax(best, bi);
+        const int a = __builtin_amdgcn_readfirstlane(bi);
+        if (a < 0) { out_kind = LEAF_NONE; break; }
+        const int child = __shfl(bC, a, 64);
+        const int an = __shfl(bN, a, 64);
+        if (lane == 0) path[depth] = ((unsigned)row << 16) | (unsigned)a;
+        depth++;
+        pl_set(me, a);                                        // games.py:79-81 place, flip player, remember action
+        Plane t = me; me = opp; opp = t;
+        last = a;
+        if (wins_through(opp, a, N, d.k)) { out_kind = LEAF_TERM_LOSS; break; }  // the side to move has lost
+        if (pl_count(me) + pl_count(opp) == G::nn) { out_kind = LEAF_TERM_DRAW; break; }
+        if (child == 0) { out_kind = LEAF_EXPAND; break; }    // mcts.py:127 node.is_leaf()
+        npar = an;
+        row = child;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) { gs.leaf[q] = me.w[q]; gs.leaf[4 + q] = opp.w[q]; }
+        gs.leaf_last = last;
+        gs.leaf_kind = out_kind;
+        gs.depth = depth;
+    }
+}
+
+// policy_fc (net.py:65) and value_fc1 + ReLU (net.py:69) of the workgroup's GP boards: one thread per output, one
+// k-ordered fmaf chain from +0, bias afterwards -- the chain v_mfma_f32_16x16x4_f32 runs in k_fc.  The weights are read
+// from the MFMA-fragment packing of az_engine.hip pack_fc: element (k, j) at ((tile*KS4PAD + k/16)*64 + (k%4)*16 + j%16)*4 + (k/4)%4.
+template <class PG, class NG>
+__device__ __forceinline__ void fc_valu(const NetWeights &w, const float *featl, float *logits_l, float *vhid_l, int tid, int nthreads)
+{
+    constexpr int nn = PG::nn, OUTS = nn + 64;
+    for (int o = tid; o < PG::G * OUTS; o += nthreads) {
+        const int g = o / OUTS, r = o - g * OUTS;
+        const bool pol = r < nn;
+        const int j = pol ? r : r - nn;
+        const int K = pol ? PG::PC * nn : PG::VC * nn;
+        const int ks4pad = pol ? NG::KS4P_PAD : NG::KS4V_PAD;
+        const float4 *wp = reinterpret_cast<const float4 *>(pol ? w.pf : w.vf) + (size_t)(j >> 4) * ks4pad * 64 + (j & 15);
+        const float *x = featl + g * PG::FROW + (pol ? 0 : PG::PC * nn);
+        float acc = 0.0f;
+        const int groups = (K + 15) / 16;
+        for (int s4 = 0; s4 < groups; s4++) {
+            const float4 w0 = wp[(size_t)s4 * 64 + 0], w1 = wp[(size_t)s4 * 64 + 16], w2 = wp[(size_t)s4 * 64 + 32], w3 = wp[(size_t)s4 * 64 + 48];
+            const float wk[16] = {w0.x, w1.x, w2.x, w3.x, w0.y, w1.y, w2.y, w3.y, w0.z, w1.z, w2.z, w3.z, w0.w, w1.w, w2.w, w3.w};
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int k = 16 * s4 + i;                       // k = 16*s4 + 4*(s%4) + kk: ascending
+                if (k < K) acc = __builtin_fmaf(x[k], wk[i], acc);
+            }
+        }
+        if (pol) logits_l[g * PG::RW + j] = acc + w.pfb[j];
+        else {
+            const float v = acc + w.vfb[j];
+            vhid_l[g * 64 + j] = v > 0.0f ? v : 0.0f;
+        }
+    }
+}
+
+// One workgroup per CU (the LDS footprint allows no second one), i.e. two waves per SIMD: let the compiler use the
+// registers that leaves (256 VGPRs) instead of spilling for an occupancy the kernel can never have.
+template <int N, int GP, bool SYNTH>
+__global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_search(DevState d, NetWeights w0, NetWeights w1)
+{
+    typedef PersistGeo<N, GP> PG;
+    typedef NetGeo<N> NG;
+    typedef TreeGeo<N> TG;
+    constexpr int NTH = AZ_NW * 64;
+    __shared__ __attribute__((aligned(16))) float lds[PG::LDSF];
+    __shared__ unsigned short wpos[PG::MR];
+    __shared__ unsigned short cellof[PG::MR];
+    __shared__ __attribute__((aligned(16))) float featl[GP * PG::FROW];
+    __shared__ float logits_l[GP * PG::RW];
+    __shared__ float vhid_l[GP * 64];
+    __shared__ unsigned path_l[GP][PG::PATH];
+    __shared__ GameLds games[GP];
+    __shared__ double sq_lds[1026];                       // np.sqrt(N + 1e-8), N = 0..S+1 (S <= 1024)
+    __shared__ int any_eval, wg_net;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // GP x R x ROWE edges
+    Edge *rows_all = reinterpret_cast<Edge *>(dyn_lds);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b0 = blockIdx.x * GP;
+    const int S = d.S;
+    for (int i = tid; i < S + 2; i += NTH) sq_lds[i] = d.sqrt_table[i];
+    // tile tables (constant over the ply)
+    for (int m = tid; m < PG::MR; m += NTH) {
+        const int g = m / PG::nn, p = m - g * PG::nn, r = p / N, c = p - r * N;
+        wpos[m] = (unsigned short)(m < PG::M ? g * PG::PP + (r + 1) * PG::PW + (c + 1) : PG::PW + 1);
+        cellof[m] = (unsigned short)(m < PG::M ? m : 0xFFFF);
+    }
+    // per-game constants of the ply in registers of the game's wave (wave g < GP owns game b0 + g)
+    const int gb = b0 + (wave < GP ? wave : 0);
+    const bool mine = wave < GP && gb < d.B && d.s_status[gb] == SLOT_ACTIVE;
+    int pl = 1, slast = -1, netid = 0, game = 0, ply = 0;
+    Plane bX{}, bO{};
+    if (mine) {
+        pl = d.s_player[gb]; slast = d.s_last[gb]; netid = d.s_net[gb]; game = d.s_game[gb]; ply = d.s_ply[gb];
+        bX = pl_load(d.board + (size_t)gb * 8); bO = pl_load(d.board + (size_t)gb * 8 + 4);
+    }
+    if (wave < GP && lane == 0) {
+        GameLds &gs = games[wave];
+        const int kind = mine ? d.leaf_kind[gb] : LEAF_NONE;       // k_begin staged the root as the pending leaf
+        for (int q = 0; q < 8; q++) gs.leaf[q] = mine ? d.leaf[(size_t)gb * 8 + q] : 0ull;
+        gs.leaf_last = mine ? d.leaf_last[gb] : -1;
+        gs.leaf_kind = kind == LEAF_ROOT ? LEAF_ROOT : LEAF_NONE;
+        gs.depth = 0;
+        gs.rows_used = 0;
+    }
+    if (tid == 0) wg_net = 0;
+    __syncthreads();
+    if (mine && lane == 0 && netid) atomicOr(&wg_net, 1);          // a workgroup's games share one net (arena: GP = 1)
+    unsigned long long cnt[4] = {0ull, 0ull, 0ull, 0ull};
+    float *inA = lds, *inB = lds + 32 * PG::CS;
+
+    for (int idx = 0; idx <= S; idx++) {
+        if (tid == 0) any_eval = 0;
+        __syncthreads();
+        if (!SYNTH) {
+            if (tid < GP && leaf_needs_net(games[tid].leaf_kind)) atomicOr(&any_eval, 1);
+            __syncthreads();
+        }
+        if (!SYNTH && any_eval) {
+            NetWeights w;                              // field-wise select: a reference to one of two argument structs would put both into scratch
+            {
+                const bool o = wg_net != 0;
+                w.c1 = o ? w1.c1 : w0.c1; w.c2 = o ? w1.c2 : w0.c2; w.c3 = o ? w1.c3 : w0.c3; w.hd = o ? w1.hd : w0.hd;
+                w.pf = o ? w1.pf : w0.pf; w.vf = o ? w1.vf : w0.vf; w.c1b = o ? w1.c1b : w0.c1b; w.c2b = o ? w1.c2b : w0.c2b;
+                w.c3b = o ? w1.c3b : w0.c3b; w.hdb = o ? w1.hdb : w0.hdb; w.pfb = o ? w1.pfb : w0.pfb; w.vfb = o ? w1.vfb : w0.vfb;
+            }
+            // ---- leaf encode + conv trunk, as trunk_group (az_net.h) on the LDS-resident leaves ----
+            {
+                float4 *z = reinterpret_cast<float4 *>(lds);
+                for (int i = tid; i < (96 * PG::CS) / 4; i += NTH) z[i] = float4{0.f, 0.f, 0.f, 0.f};
+            }
+            __syncthreads();
+            for (int m = tid; m < PG::MR; m += NTH) {          // games.py:86-129 encode
+                const int cell = cellof[m];
+                if (cell != 0xFFFF) {
+                    const int g = cell / PG::nn, p = cell - g * PG::nn;
+                    const GameLds &gs = games[g];
+                    const int pos = wpos[m];
+                    if ((gs.leaf[p >> 6] >> (p & 63)) & 1ull) inB[pos] = 1.0f;
+                    if ((gs.leaf[4 + (p >> 6)] >> (p & 63)) & 1ull) inB[PG::CS + pos] = 1.0f;
+                    if (gs.leaf_last == p) inB[2 * PG::CS + pos] = 1.0f;
+                }
+            }
+            __syncthreads();
+            conv_layer<PG, 4, 32, CONV_OUT_PACKED>(inB, inA, w.c1, w.c1b, wpos, cellof, wave, lane);
+            __syncthreads();
+            for (int i = tid; i < 3 * PG::CS; i += NTH) inB[i] = 0.0f;
+            __syncthreads();
+            conv_layer<PG, 32, 64, CONV_OUT_PACKED>(inA, inB, w.c2, w.c2b, wpos, cellof, wave, lane);
+            __syncthreads();
+            conv_layer<PG, 64, 128, CONV_OUT3>(inB, lds, w.c3, w.c3b, wpos, cellof, wave, lane);
+            __syncthreads();
+            // policy_conv (128->4) and value_conv (128->2), 1x1, into the LDS feature rows
+            {
+                const int q = lane >> 4, r16 = lane & 15;
+                const float4 *wp4 = reinterpret_cast<const float4 *>(w.hd) + lane;
+                float hb[4];
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) hb[rg] = (q * 4 + rg) < 6 ? w.hdb[q * 4 + rg] : 0.0f;
+                for (int mt = wave; mt < PG::MT; mt += AZ_NW) {
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const float *ip = lds + q * PG::CS3 + mt * 16 + r16;
+#pragma unroll
+                    for (int s4 = 0; s4 < 8; s4++) {
+                        const float4 bq = wp4[s4 * 64];
+                        acc = mfma4(bq.x, ip[(s4 * 16 + 0) * PG::CS3], acc);
+                        acc = mfma4(bq.y, ip[(s4 * 16 + 4) * PG::CS3], acc);
+                        acc = mfma4(bq.z, ip[(s4 * 16 + 8) * PG::CS3], acc);
+                        acc = mfma4(bq.w, ip[(s4 * 16 + 12) * PG::CS3], acc);
+                    }
+                    const int cell = cellof[mt * 16 + r16];
+                    if (cell != 0xFFFF) {
+                        const int g = cell / PG::nn, p = cell - g * PG::nn;
+#pragma unroll
+                        for (int rg = 0; rg < 4; rg++) {
+                            const int j = q * 4 + rg;     // head channel: 0-3 policy_conv, 4-5 value_conv (net.py:64,69 flatten order)
+                            if (j < 6) {
+                                float v = acc[rg] + hb[rg];
+                                featl[g * PG::FROW + j * PG::nn + p] = v > 0.0f ? v : 0.0f;
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            fc_valu<PG, NG>(w, featl, logits_l, vhid_l, tid, NTH);
+            __syncthreads();
+        }
+        // ---- tree step: wave g works on game g ----
+        if (mine)
+            step_lds<N, PG, SYNTH>(d, gb, lane, rows_all + (size_t)wave * d.R * PG::ROWE, path_l[wave], games[wave],
+                                   logits_l + wave * PG::RW, vhid_l + wave * 64, sq_lds, idx, idx < S ? 1 : 0, pl, slast, netid,
+                                   game, ply, bX, bO, cnt);
+        __syncthreads();
+    }
+    // ---- hand the root row to k_move (visit counts -> pi -> move), counters to the host ----
+    if (mine) {
+        const Edge *root = rows_all + (size_t)wave * d.R * PG::ROWE;
+        Edge *out = d.edges + (size_t)gb * d.R * TG::RW;
+        if (lane < PG::ROWE) out[lane] = root[lane];
+        if (lane == 0) {
+            d.rows_used[gb] = games[wave].rows_used;
+            d.leaf_kind[gb] = LEAF_NONE;
+            unsigned long long *c = d.cnt + (size_t)gb * CNT_STRIDE;
+            c[0] += cnt[0]; c[1] += cnt[1]; c[2] += cnt[2]; c[3] += cnt[3];
+        }
+    }
+}

@@ -1,0 +1,98 @@
+"""The persistent search kernel (csrc/az_search.h: one launch per ply, trees in LDS) against the lock-step pipeline
+(k_trunk -> k_fc -> k_step per simulation) it replaces on small boards, and against the oracle.  Same fma chains, same
+operator order: everything is bit-identical.  AZ_PERSIST=0 selects the lock-step pipeline."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc
+from tests.util import weights_from_fixture
+
+import alphazero_piskvorky_amd as az
+from alphazero_piskvorky_amd.weights import synthetic_state_dict
+
+WORK = ("games", "plies", "records", "simulations", "expansions", "root_evals", "terminal_hits", "depth_sum", "trunk_boards")
+
+
+def _run(monkeypatch, persist, n, k, S, slots, G, synthetic, sd, cut=0, arena_games=0, sd2=None):
+    monkeypatch.setenv("AZ_PERSIST", persist)
+    e = az.Engine(n, k, S, slots, synthetic=synthetic, log_table=orc.numpy_log_table(S))
+    if not synthetic:
+        e.load_weights(sd, 0)
+        e.load_weights(sd2 if sd2 is not None else sd, 1)
+    c = e.selfplay(G, seed0=1357, max_plies=cut)
+    out = dict(rec=e.records(), games=e.games(), c=c)
+    if arena_games:
+        out["arena"] = e.arena(arena_games, seed0=24, temperature_table=orc.arena_T_table(n * n))
+    board = np.zeros(n * n, np.uint8); board[n + 1] = 1; board[2 * n + 2] = 2
+    out["search"] = e.search(board, 1, 2 * n + 2, 0.6, np.random.RandomState(3).dirichlet([0.3] * (n * n - 2)), 0.81)
+    e.close()
+    return out
+
+
+@pytest.mark.parametrize("n,k,S,slots,G,synthetic", [(5, 4, 100, 7, 23, False), (5, 4, 100, 8, 20, True), (5, 4, 150, 5, 9, False),
+                                                     (6, 4, 60, 6, 10, False), (7, 5, 40, 4, 6, False), (3, 3, 30, 4, 12, False),
+                                                     (4, 3, 1, 3, 5, True)])
+def test_persistent_kernel_equals_the_lockstep_pipeline(monkeypatch, n, k, S, slots, G, synthetic):
+    """Whole episodes with refill (odd slot counts leave a workgroup with a single game), the arena (one game per
+    workgroup, two nets) and a single search, persistent kernel vs lock-step kernels: identical records and counters."""
+    sd = weights_from_fixture(5, "ckpt_saved") if n == 5 else synthetic_state_dict(n)
+    sd2 = weights_from_fixture(5, "ckpt_0802") if n == 5 else synthetic_state_dict(n, seed=7)
+    a = _run(monkeypatch, "0", n, k, S, slots, G, synthetic, sd, arena_games=0 if synthetic else 5, sd2=sd2)
+    b = _run(monkeypatch, "1", n, k, S, slots, G, synthetic, sd, arena_games=0 if synthetic else 5, sd2=sd2)
+    for key in a["rec"]:
+        assert np.array_equal(a["rec"][key], b["rec"][key]), key
+    assert np.array_equal(a["games"][0], b["games"][0]) and np.array_equal(a["games"][1], b["games"][1])
+    for key in WORK:
+        assert a["c"][key] == b["c"][key], key
+    if "arena" in a:
+        assert np.array_equal(a["arena"]["actions"], b["arena"]["actions"]) and np.array_equal(a["arena"]["results"], b["arena"]["results"])
+    for key in ("N", "W", "P", "pi"):
+        assert np.array_equal(a["search"][key], b["search"][key]), key
+    assert a["search"]["action"] == b["search"]["action"]
+    # one launch per ply instead of three per simulation: the lock-step pipeline counts (S + 1) trunk launches per ply
+    assert synthetic or b["c"]["trunk_launches"] * (S + 1) == a["c"]["trunk_launches"]
+
+
+def test_persistent_kernel_full_5x5_games_vs_oracle(monkeypatch):
+    """BASELINE configs[1] shape (5x5 / 4-in-a-row, 100 simulations, trained checkpoint) on the persistent kernel, complete
+    games against the oracle: moves, boards, visit counts, pi bit patterns, z, expansion totals."""
+    monkeypatch.setenv("AZ_PERSIST", "1")
+    n, k, S, G = 5, 4, 100, 24
+    sd = weights_from_fixture(5, "ckpt_saved")
+    e = az.Engine(n, k, S, 16, log_table=orc.numpy_log_table(S))
+    e.load_weights(sd, 0)
+    c = e.selfplay(G, seed0=777)
+    rec = e.records(); nply, res = e.games()
+    e.close()
+    o = orc.Oracle(n, k, S); onet = orc.Net(n, sd)
+    off = 0; exp = term = dsum = 0
+    for g in range(G):
+        noise, us = orc.selfplay_tape(777 + g, n)
+        r = o.selfplay_game(onet, noise, us)
+        L = int(nply[g]); sl = slice(off, off + L)
+        assert L == r["nply"] and int(res[g]) == r["result"]
+        for key in ("actions", "boards", "movers", "visits", "pis", "z", "lasts"):
+            assert np.array_equal(rec[key][sl], r[key]), f"game {g}: {key} differs from the oracle"
+        exp += r["counters"]["expansions"]; term += r["counters"]["terminal_hits"]; dsum += r["counters"]["depth_sum"]
+        off += L
+    assert (c["expansions"], c["terminal_hits"], c["depth_sum"]) == (exp, term, dsum)
+
+
+def test_persistent_kernel_steps_aside_when_it_does_not_apply(monkeypatch):
+    """Trees that do not fit into LDS (5x5 with 400 simulations) run on the lock-step pipeline; results stay the oracle's."""
+    monkeypatch.setenv("AZ_PERSIST", "1")
+    n, k = 5, 4
+    sd = weights_from_fixture(5, "ckpt_saved")
+    e = az.Engine(n, k, 400, 4, log_table=orc.numpy_log_table(400))
+    e.load_weights(sd, 0)
+    c = e.selfplay(3, seed0=5, max_plies=3)
+    rec = e.records()
+    e.close()
+    assert c["trunk_launches"] == 401 * 3          # lock-step: one trunk launch per evaluation batch
+    o = orc.Oracle(n, k, 400); onet = orc.Net(n, sd)
+    for g in range(3):
+        noise, us = orc.selfplay_tape(5 + g, n)
+        r = o.selfplay_game(onet, noise, us, maxply=3)
+        assert np.array_equal(rec["visits"][3 * g:3 * g + 3], r["visits"]) and np.array_equal(rec["pis"][3 * g:3 * g + 3], r["pis"])
