@@ -27,7 +27,7 @@ AZ_MODEL_PLAIN, AZ_MODEL_RESNET = 0, 1
 EXPORTS = [
     "az_create", "az_destroy", "az_last_error", "az_load_weights", "az_load_weights_resnet", "az_net_eval", "az_search", "az_selfplay",
     "az_selfplay_begin", "az_selfplay_step", "az_selfplay_end", "az_selfplay_games", "az_selfplay_records", "az_record_bytes", "az_selfplay_pack", "az_examples_from_packed",
-    "az_examples_gather", "az_arena", "az_rules_replay", "az_rng_selfplay_tape", "az_rng_uniforms", "az_set_profiling", "az_set_subtree_reuse", "az_get_counters", "az_get_lanes", "az_set_virtual_loss", "az_set_eval_cache",
+    "az_examples_gather", "az_arena", "az_rules_replay", "az_rng_selfplay_tape", "az_rng_uniforms", "az_set_profiling", "az_set_subtree_reuse", "az_get_counters", "az_get_lanes", "az_get_persistent", "az_set_virtual_loss", "az_set_eval_cache",
 ]
 
 
@@ -340,6 +340,10 @@ class Engine:
     def lanes(self):
         """Number of lanes (streams + driver threads) inside the engine, az_config.engines after the library's choice."""
         return int(lib().az_get_lanes(self.h))
+
+    def persistent(self):
+        """Games per workgroup of the persistent search kernel in the last / open episode, 0 = lock-step pipeline."""
+        return int(lib().az_get_persistent(self.h))
 
     def counters(self):
         c = az_counters()

@@ -424,7 +424,7 @@ static int alloc_items(az_engine *e, Lane &L, int leaves)
     ALLOC(dbg, (NI * 16 + 4096 * 32) * sizeof(unsigned long long));
 #endif
     if (e->split_max > 0)    // zeroed once: the padding ring of the packed images is never written afterwards
-        ALLOC(scratch, (size_t)e->ops->split_scratch_floats((int)NI) * sizeof(float));
+        ALLOC(scratch, (size_t)e->ops->split_scratch_floats((int)NI, e->cfg.model) * sizeof(float));
     if (leaves > 1) { ALLOC(it_status, NI * 4); ALLOC(it_net, NI * 4); }
 #undef ALLOC
     if (rc) return rc;
@@ -486,11 +486,9 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
         return rc;
     }
     e->stream = e->lanes[0].stream;
-    if (cfg->model == AZ_MODEL_PLAIN) {
+    {
         const char *sm = getenv("AZ_SPLIT_MAX");      // 0 disables the split trunk, a large value forces it
         if (sm) e->split_max = atoi(sm);
-    } else {
-        e->split_max = 0;
     }
     int rc = AZ_OK;
     for (int i = 0; i < K && !rc; i++) {
@@ -1520,3 +1518,5 @@ extern "C" int az_set_eval_cache(az_engine *e, int64_t entries)
     each_state(e, [&](DevState &d) { d.cache = (float *)e->cache.p; d.cache_mask = e->cache_mask; d.cache_gen = e->cache_gen; });
     return AZ_OK;
 }
+
+extern "C" int az_get_persistent(const az_engine *e) { return e ? e->persist_gp : AZ_ERR_INVALID; }

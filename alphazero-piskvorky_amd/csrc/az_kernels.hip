@@ -27,6 +27,19 @@ void trunk(const LaunchCtx &c, int net_id)
 
 void trunk_split(const LaunchCtx &c, int net_id)
 {
+    if (c.model == 1) {
+        typedef ResGeo<N> G;
+        const int ngroups = (c.dv.B + G::G - 1) / G::G;
+        dim3 bt(G::NW * 64);
+        const ResWeights &w = c.rw[net_id];
+        hipLaunchKernelGGL((k_split_res<N, 0>), dim3(ngroups, 4), bt, 0, c.stream, c.dv, w.stem, w.stemb, net_id, c.scratch, c.feat);
+        for (int blk = 0; blk < 3; blk++) {
+            hipLaunchKernelGGL((k_split_res<N, 1>), dim3(ngroups, 4), bt, 0, c.stream, c.dv, w.blk[2 * blk], w.blkb[2 * blk], net_id, c.scratch, c.feat);
+            hipLaunchKernelGGL((k_split_res<N, 2>), dim3(ngroups, 4), bt, 0, c.stream, c.dv, w.blk[2 * blk + 1], w.blkb[2 * blk + 1], net_id, c.scratch, c.feat);
+        }
+        hipLaunchKernelGGL((k_split_res<N, 3>), dim3(ngroups), bt, 0, c.stream, c.dv, w.hd, w.hdb, net_id, c.scratch, c.feat);
+        return;
+    }
     typedef NetGeo<N> G;
     const int ngroups = (c.dv.B + G::G - 1) / G::G;
     dim3 bt(G::NW * 64);
@@ -36,8 +49,9 @@ void trunk_split(const LaunchCtx &c, int net_id)
     hipLaunchKernelGGL((k_split<N, 4>), dim3(ngroups), bt, 0, c.stream, c.dv, c.w[net_id], net_id, c.scratch, c.feat);
 }
 
-long long split_scratch_floats(int slots)
+long long split_scratch_floats(int slots, int model)
 {
+    if (model == 1) return (long long)((slots + ResGeo<N>::G - 1) / ResGeo<N>::G) * ResSplitGeo<N>::PER_GROUP;
     typedef NetGeo<N> G;
     return (long long)((slots + G::G - 1) / G::G) * SplitGeo<N>::PER_GROUP;
 }
@@ -83,6 +97,7 @@ void root_cache(const LaunchCtx &c)
 }
 
 constexpr bool HAS_SEARCH = N <= 7;      // the LDS-resident tree needs (S + 1) * n*n * 16 B per game
+constexpr bool HAS_SEARCH2 = N <= 5;     // two games per workgroup: beyond 5x5 the rows of two games never fit beside the image
 
 template <int GP, bool SY>
 int search_prepare_t(int S)
@@ -102,7 +117,10 @@ int search_prepare_t(int S)
 
 int search_prepare(int S, int games, int synthetic)
 {
-    if (games == 2) return synthetic ? search_prepare_t<2, true>(S) : search_prepare_t<2, false>(S);
+    if (games == 2) {
+        if constexpr (HAS_SEARCH2) return synthetic ? search_prepare_t<2, true>(S) : search_prepare_t<2, false>(S);
+        return 0;
+    }
     if (games == 1) return synthetic ? search_prepare_t<1, true>(S) : search_prepare_t<1, false>(S);
     return 0;
 }
@@ -122,7 +140,10 @@ void search_t(const LaunchCtx &c)
 
 void search(const LaunchCtx &c, int games)
 {
-    if (games == 2) search_t<2>(c); else search_t<1>(c);
+    if constexpr (HAS_SEARCH2) {
+        if (games == 2) { search_t<2>(c); return; }
+    }
+    search_t<1>(c);
 }
 
 void move(const LaunchCtx &c)

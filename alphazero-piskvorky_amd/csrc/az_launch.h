@@ -22,8 +22,8 @@ struct LaunchCtx {
 
 struct SizeOps {
     void (*trunk)(const LaunchCtx &, int net_id);
-    void (*trunk_split)(const LaunchCtx &, int net_id);     // plain net only; same results, lower latency for few boards
-    long long (*split_scratch_floats)(int slots);
+    void (*trunk_split)(const LaunchCtx &, int net_id);     // same results as trunk, lower latency for few boards
+    long long (*split_scratch_floats)(int slots, int model);
     void (*fc)(const LaunchCtx &, int net_id);
     void (*step)(const LaunchCtx &, int rootN, int do_select);
     void (*step_vl)(const LaunchCtx &, int sims_done, int nb_next);      // virtual-loss batching (DevState.L leaves per game)

@@ -706,6 +706,136 @@ __global__ __launch_bounds__(ResGeo<N>::NW * 64) void k_trunk_res(DevState d, Re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split trunk for the ResidualBlock net: the low-latency path (few pending boards: the arena, episode tails, single
+// searches), like k_split for GomokuNet.  Every conv is its own launch and a board group's four 16-channel tiles go to
+// four workgroups; the 64-channel packed images A (block input/output) and B (intermediate) cross HBM/L2 in the scratch
+// of the group (padding ring zeroed once at allocation, never written).  Same fma chains as k_trunk_res: bit-identical.
+//   KIND 0: encode + stem             grid (groups, 4) -> A
+//   KIND 1: block conv1               grid (groups, 4)    A -> B
+//   KIND 2: block conv2 + skip, ReLU  grid (groups, 4)    B -> A (in place: a workgroup reads and writes only its own channel tile of A)
+//   KIND 3: 1x1 heads                 grid (groups)       A -> feature rows
+// ------------------------------------------------------------------------------------------------
+template <int N>
+struct ResSplitGeo {
+    typedef ResGeo<N> G;
+    static constexpr int IMG = 64 * G::CS;
+    static constexpr int PER_GROUP = 2 * IMG;                 // floats of scratch per board group
+};
+
+template <class G>
+__device__ __forceinline__ bool split_prologue_g(const DevState &d, int net_id, int b0, unsigned short *wpos,
+                                                 unsigned short *cellof, int *any_active, int tid)
+{
+    if (tid == 0) *any_active = 0;
+    __syncthreads();
+    if (tid < G::G) {
+        int b = b0 + tid;
+        if (b < d.B) {
+            int kind = d.leaf_kind[b];
+            if (leaf_needs_net(kind) && d.s_status[b] == SLOT_ACTIVE && d.s_net[b] == net_id) atomicOr(any_active, 1);
+        }
+    }
+    for (int m = tid; m < G::MR; m += G::NW * 64) {
+        int pos, cell;
+        if constexpr (G::ROWT) {
+            const int t = m >> 4, c = m & 15, g = t / G::n, r = t - g * G::n;
+            pos = g * G::PP + (r + 1) * G::PW + (c + 1);
+            cell = c < G::n ? g * G::nn + r * G::n + c : 0xFFFF;
+        } else {
+            const int g = m / G::nn, p = m - g * G::nn, r = p / G::n, c = p - r * G::n;
+            pos = m < G::M ? g * G::PP + (r + 1) * G::PW + (c + 1) : G::PW + 1;
+            cell = m < G::M ? m : 0xFFFF;
+        }
+        wpos[m] = (unsigned short)pos;
+        cellof[m] = (unsigned short)cell;
+    }
+    __syncthreads();
+    return *any_active != 0;
+}
+
+template <int N, int KIND>
+__global__ __launch_bounds__(ResGeo<N>::NW * 64) void k_split_res(DevState d, const float *__restrict__ wp, const float *__restrict__ bias,
+                                                                  int net_id, float *__restrict__ scratch, float *__restrict__ feat)
+{
+    typedef ResGeo<N> G;
+    constexpr int NTH = G::NW * 64;
+    constexpr int LDSF = KIND == 0 ? 4 * G::CS : 64 * G::CS;
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+    __shared__ unsigned short wpos[G::MR];
+    __shared__ unsigned short cellof[G::MR];
+    __shared__ int any_active;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = blockIdx.x, b0 = grp * G::G;
+    if (!split_prologue_g<G>(d, net_id, b0, wpos, cellof, &any_active, tid)) return;
+    float *A = scratch + (size_t)grp * ResSplitGeo<N>::PER_GROUP, *B = A + ResSplitGeo<N>::IMG;
+    if constexpr (KIND == 0) {
+        for (int i = tid; i < LDSF; i += NTH) lds[i] = 0.0f;
+        __syncthreads();
+        for (int m = tid; m < G::MR; m += NTH) {          // games.py:86-129 encode
+            const int cell = cellof[m];
+            if (cell != 0xFFFF) {
+                const int g = cell / G::nn, p = cell - g * G::nn;
+                const int b = b0 + g;
+                if (b < d.B) {
+                    const u64 *lf = d.leaf + (size_t)b * 8;
+                    const int pos = wpos[m];
+                    if ((lf[p >> 6] >> (p & 63)) & 1ull) lds[pos] = 1.0f;
+                    if ((lf[4 + (p >> 6)] >> (p & 63)) & 1ull) lds[G::CS + pos] = 1.0f;
+                    if (d.leaf_last[b] == p) lds[2 * G::CS + pos] = 1.0f;
+                }
+            }
+        }
+        __syncthreads();
+        conv_layer<G, 4, 64, CONV_OUT_PACKED, 1>(lds, A, wp, bias, wpos, cellof, wave, lane, blockIdx.y);
+    } else {
+        const float4 *src = reinterpret_cast<const float4 *>(KIND == 2 ? B : A);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = tid; i < LDSF / 4; i += NTH) dst[i] = src[i];
+        __syncthreads();
+        if constexpr (KIND == 1) conv_layer<G, 64, 64, CONV_OUT_PACKED, 1>(lds, B, wp, bias, wpos, cellof, wave, lane, blockIdx.y);
+        else if constexpr (KIND == 2) conv_layer<G, 64, 64, CONV_OUT_RESIDUAL, 1>(lds, A, wp, bias, wpos, cellof, wave, lane, blockIdx.y);
+        else {
+            // heads: D[head channel][cell] over the packed trunk image, 16 k-steps (64 channels); wp = packed head rows, bias = folded biases [3]
+            const int q = lane >> 4, r16 = lane & 15;
+            const float4 *wp4 = reinterpret_cast<const float4 *>(wp) + lane;
+            const float4 *in4 = reinterpret_cast<const float4 *>(lds);
+            float hb[4];
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) hb[rg] = (q * 4 + rg) < (G::PC + G::VC) ? bias[q * 4 + rg] : 0.0f;
+            for (int mt = wave; mt < G::MT; mt += G::NW) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int base = q * G::CS + (int)wpos[mt * 16 + r16];
+#pragma unroll
+                for (int cg = 0; cg < 4; cg++) {
+                    const float4 a = in4[base + cg * 4 * G::CS];
+                    const float4 wq = wp4[cg * 64];
+                    acc = mfma4(wq.x, a.x, acc);
+                    acc = mfma4(wq.y, a.y, acc);
+                    acc = mfma4(wq.z, a.z, acc);
+                    acc = mfma4(wq.w, a.w, acc);
+                }
+                const int cell = cellof[mt * 16 + r16];
+                if (cell != 0xFFFF) {
+                    const int g = cell / G::nn, p = cell - g * G::nn;
+                    const int b = b0 + g;
+                    if (b < d.B && d.s_net[b] == net_id) {
+#pragma unroll
+                        for (int rg = 0; rg < 4; rg++) {
+                            const int j = q * 4 + rg;     // 0-1 policy_conv, 2 value_conv
+                            if (j < G::PC + G::VC) {
+                                float v = acc[rg] + hb[rg];
+                                feat[(size_t)b * G::FROW + j * G::nn + p] = v > 0.0f ? v : 0.0f;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // policy_fc (net.py:65) and value_fc1 + ReLU (net.py:69) for 16 boards per workgroup row.
 template <class G>
 __global__ __launch_bounds__(G::FCW * 64) void k_fc(DevState d, NetWeights w, int net_id, const float *__restrict__ feat,

@@ -213,6 +213,7 @@ def main():
     else:
         eng.selfplay_end()
 
+    persist = eng.persistent()
     if rank == 0:
         trunk_f, fc_f = net_flops(n, a.model)
         boards = cal["expansions"] + cal["plies"]        # boards the trunk kernel evaluated in the calibration ply
@@ -250,7 +251,7 @@ def main():
         fc_ms = (cal["nn_seconds"] - cal["trunk_seconds"]) * 1e3 / launches
         fc_bytes = fc_w_bytes + (boards / launches) * (feat_in + 4 * nn_cells + 4)
         fc_gbs = fc_bytes / (fc_ms * 1e-3) / 1e9 if fc_ms > 0 else 0.0
-        rest = [
+        rest = [] if persist else [
             {"kernel": f"k_step<{n}> (softmax/value tail, backup, PUCT select, expand; one wavefront per game)", "bound": "hbm",
              "achieved": step_gbs, "peak": 8000.0, "unit": "GB/s", "frac": step_gbs / 8000.0, "avg_launch_ms": step_ms,
              "games_per_launch": games_cal, "bytes_per_simulation": bytes_sim, "mean_select_depth": dbar,
@@ -267,7 +268,8 @@ def main():
             "collectives": (td.get_backend() if dist else None),
             "config": {"workload": f"{n}x{n} / {k}-in-a-row self-play, {B} concurrent games per GPU, {S} sims/move "
                                    f"{'(BASELINE.json configs[3] per-GPU shard)' if (n, k, S, B, a.model) == (15, 5, 400, 1024, 'plain') else '(custom)'}, {'GomokuNet' if a.model == 'plain' else 'ResidualBlock net'} random-init weights, numpy-compatible RNG tapes{', SUBTREE REUSE ON (not the reference algorithm)' if a.subtree_reuse else ''}{f', VIRTUAL-LOSS BATCHES OF {a.virtual_loss} (not the reference algorithm)' if a.virtual_loss > 1 else ''}{f', evaluation cache of {a.eval_cache} entries (results unchanged)' if a.eval_cache else ''}",
-                       "board": n, "win_length": k, "sims_per_move": S, "games_per_gpu": B, "engines_per_gpu": a.engines, "parallelism": f"games sharded x{world}" + (" (ranks sharing GPUs, gloo rehearsal)" if share else "")},
+                       "board": n, "win_length": k, "sims_per_move": S, "games_per_gpu": B, "engines_per_gpu": a.engines,
+                       "search_kernel": f"persistent ({persist} games per workgroup, trees in LDS)" if persist else "lock-step (k_trunk, k_fc, k_step per evaluation batch)", "parallelism": f"games sharded x{world}" + (" (ranks sharing GPUs, gloo rehearsal)" if share else "")},
             "per_gpu_node_expansions_per_sec": exp_all / dt / world,
             "simulations_per_sec": sims_all / dt, "plies_per_sec": plies_all / dt,
             "mean_select_depth": depth_all / max(sims_all, 1), "terminal_hit_fraction": term_all / max(sims_all, 1),
@@ -275,7 +277,9 @@ def main():
             "self_play_games_per_sec": None if episode is None else episode["games_per_sec"],
             "self_play_games_per_sec_steady_state": None if episode is None or "steady_state" not in episode else episode["steady_state"]["games_per_sec"],
             "episode": episode,
-            "roofline": {"kernel": (f"k_trunk<{n}> (encode+conv1+conv2+conv3+head convs, LDS-resident, v_mfma_f32_16x16x4_f32)" if a.model == "plain"
+            "roofline": {"kernel": (f"k_search<{n},{persist}> (persistent: one launch per ply = {S + 1} x [encode+conv trunk+heads (MFMA), FC layers, tree step], "
+                                    f"{persist} games per workgroup, trees in LDS; priced with the trunk FLOPs only)" if persist
+                                    else f"k_trunk<{n}> (encode+conv1+conv2+conv3+head convs, LDS-resident, v_mfma_f32_16x16x4_f32)" if a.model == "plain"
                                     else f"k_trunk_res<{n}> (encode+stem+3 residual blocks+head convs, LDS-resident, v_mfma_f32_16x16x4_f32)"),
                          "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": avg_ms, "boards_per_launch": boards / launches,

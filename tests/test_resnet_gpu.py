@@ -11,6 +11,9 @@ from alphazero_piskvorky_amd.net import GomokuResNet, fold_resnet_state_dict
 from alphazero_piskvorky_amd.weights import synthetic_resnet_state_dict
 
 
+SPLIT_MODES = ["0", "1000000"]     # AZ_SPLIT_MAX: fused k_trunk_res only | split (low-latency) trunk forced
+
+
 def _positions(rs, n, cnt):
     boards = np.zeros((cnt, n * n), np.uint8); players = np.zeros(cnt, np.uint8); lasts = -np.ones(cnt, np.int16)
     for i in range(cnt):
@@ -22,8 +25,10 @@ def _positions(rs, n, cnt):
     return boards, players, lasts
 
 
+@pytest.mark.parametrize("split", SPLIT_MODES)
 @pytest.mark.parametrize("n", [5, 9, 15])
-def test_resnet_forward_bit_exact_vs_oracle_and_close_to_torch(n):
+def test_resnet_forward_bit_exact_vs_oracle_and_close_to_torch(n, split, monkeypatch):
+    monkeypatch.setenv("AZ_SPLIT_MAX", split)
     sd = synthetic_resnet_state_dict(n)
     folded = fold_resnet_state_dict(sd)
     e = az.Engine(n, 5 if n > 5 else 4, 8, 16, model="resnet")
@@ -47,8 +52,10 @@ def test_resnet_forward_bit_exact_vs_oracle_and_close_to_torch(n):
     e.close()
 
 
+@pytest.mark.parametrize("split", SPLIT_MODES)
 @pytest.mark.parametrize("n,k,S,G,cut", [(5, 4, 40, 5, 0), (9, 5, 24, 4, 5), (15, 5, 16, 3, 3)])
-def test_resnet_selfplay_bit_exact_vs_oracle(n, k, S, G, cut):
+def test_resnet_selfplay_bit_exact_vs_oracle(n, k, S, G, cut, split, monkeypatch):
+    monkeypatch.setenv("AZ_SPLIT_MAX", split)
     sd = synthetic_resnet_state_dict(n)
     e = az.Engine(n, k, S, 3, model="resnet", log_table=orc.numpy_log_table(S))
     e.load_weights(sd, 0)
@@ -109,6 +116,9 @@ def test_resnet_arena_and_shims():
     assert np.isfinite(out["loss"])
 
 
+_ORACLE_CACHE = {}
+
+
 def _host_threads():
     import os
     return max(1, min(16, os.cpu_count() or 1))
@@ -162,10 +172,12 @@ def test_config4_resnet_15x15_800sims_complete_games_bit_exact_vs_oracle():
             assert int(rec["actions"][ri]) == r["action"]
 
 
-def test_config4_resnet_15x15_arena_bit_exact_vs_oracle():
+@pytest.mark.parametrize("split", SPLIT_MODES)
+def test_config4_resnet_15x15_arena_bit_exact_vs_oracle(split, monkeypatch):
     """configs[4]'s head-to-head arena (evaluator.py:50-104) on the 15x15 ResidualBlock net: 4 games at 200 simulations
     (NUM_EVAL_SIMULATIONS, constants.py) between two weight sets, engine vs the oracle's free-running games."""
     from concurrent.futures import ThreadPoolExecutor
+    monkeypatch.setenv("AZ_SPLIT_MAX", split)
     n, k, S, G, seed0 = 15, 5, 200, 4, 8800
     a, b = synthetic_resnet_state_dict(n, 1), synthetic_resnet_state_dict(n, 2)
     e = az.Engine(n, k, S, G, model="resnet", log_table=orc.numpy_log_table(S))
@@ -179,8 +191,10 @@ def test_config4_resnet_15x15_arena_bit_exact_vs_oracle():
     def one(g):
         return o.arena_game(oa, ob, g, np.random.RandomState(seed0 + g).random_sample(n * n))
 
-    with ThreadPoolExecutor(min(G, _host_threads())) as ex:
-        outs = list(ex.map(one, range(G)))
+    if "arena" not in _ORACLE_CACHE:               # the oracle's games are the same for both trunk variants
+        with ThreadPoolExecutor(min(G, _host_threads())) as ex:
+            _ORACLE_CACHE["arena"] = list(ex.map(one, range(G)))
+    outs = _ORACLE_CACHE["arena"]
     w = l = d = 0
     for g, ro in enumerate(outs):
         assert int(r["nply"][g]) == ro["nply"] and int(r["results"][g]) == ro["result"], f"arena game {g}"

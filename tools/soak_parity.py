@@ -24,7 +24,7 @@ if "ckpt" in sys.argv[6:]:
 else:
     sd = synthetic_resnet_state_dict(n) if model == "resnet" else synthetic_state_dict(n)
 slots = max(4, G // 2)                                       # fewer slots than games: refills are part of the soak
-eng = az.MultiEngine(n, k, S, slots, engines=4, log_table=orc.numpy_log_table(S), model=model)
+eng = az.Engine(n, k, S, slots, log_table=orc.numpy_log_table(S), model=model)
 eng.load_weights(sd, 0)
 eng.set_subtree_reuse(reuse)
 t0 = time.perf_counter()
