@@ -25,7 +25,7 @@ AZ_AUG_NONE, AZ_AUG_REFERENCE4, AZ_AUG_DIHEDRAL8 = 1, 4, 8
 AZ_MODEL_PLAIN, AZ_MODEL_RESNET = 0, 1
 
 EXPORTS = [
-    "az_create", "az_destroy", "az_last_error", "az_load_weights", "az_load_weights_resnet", "az_net_eval", "az_search", "az_selfplay",
+    "az_create", "az_destroy", "az_last_error", "az_load_weights", "az_load_weights_resnet", "az_net_eval", "az_search", "az_search_callback", "az_selfplay",
     "az_selfplay_begin", "az_selfplay_step", "az_selfplay_end", "az_selfplay_games", "az_selfplay_records", "az_record_bytes", "az_selfplay_pack", "az_examples_from_packed",
     "az_examples_gather", "az_arena", "az_rules_replay", "az_rng_selfplay_tape", "az_rng_uniforms", "az_set_profiling", "az_set_subtree_reuse", "az_get_counters", "az_get_lanes", "az_get_persistent", "az_set_virtual_loss", "az_set_eval_cache",
 ]
@@ -223,6 +223,43 @@ class Engine:
         a = C.c_int32(-1)
         self._check(lib().az_search(self.h, int(slot), _p(board), int(player), int(last), C.c_double(temperature),
                                     _dp(nz), C.c_double(u), _p(pi), C.byref(a), _p(N), _p(W), _p(P)), "az_search")
+        return dict(action=int(a.value), pi=pi, N=N, W=W, P=P)
+
+    _EVAL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float))
+
+    def search_callback(self, board, player, last, temperature, fn, noise=None, u=0.5):
+        """MCTS.run with the evaluator on the host (az_search_callback): fn(cells uint8[n*n], player, last) -> (policy
+        float32[n*n] or [n,n], value).  One host round trip per simulation: the compatibility path for arbitrary
+        policy_value_fn callables (mcts.py:87-93)."""
+        board = np.ascontiguousarray(board, np.uint8).reshape(self.nn)
+        nz = None if noise is None else np.ascontiguousarray(noise, np.float64)
+        if nz is not None and len(nz) != int((board == 0).sum()):
+            raise ValueError("noise must have one entry per legal cell")
+        nn = self.nn
+        err = []
+
+        def _cb(user, b, pl, la, pol, val):
+            try:
+                cells = np.ctypeslib.as_array(b, shape=(nn,)).copy()
+                P, v = fn(cells, int(pl), int(la))
+                if hasattr(P, "detach"):
+                    P = P.detach().cpu().numpy()
+                np.ctypeslib.as_array(pol, shape=(nn,))[:] = np.asarray(P, dtype=np.float32).reshape(nn)
+                val[0] = float(v)
+                return 0
+            except Exception as ex:       # nothing may propagate through the C frames
+                err.append(ex)
+                return 1
+
+        cb = self._EVAL_CB(_cb)
+        pi = np.zeros(nn, np.float32); N = np.zeros(nn, np.int32)
+        W = np.zeros(nn, np.float64); P = np.zeros(nn, np.float32)
+        a = C.c_int32(-1)
+        rc = lib().az_search_callback(self.h, _p(board), int(player), int(last), C.c_double(temperature), _dp(nz), C.c_double(u),
+                                      cb, None, _p(pi), C.byref(a), _p(N), _p(W), _p(P))
+        if err:
+            raise err[0]
+        self._check(rc, "az_search_callback")
         return dict(action=int(a.value), pi=pi, N=N, W=W, P=P)
 
     # ---- self-play ----

@@ -514,7 +514,7 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
         d.cnt = (unsigned long long *)L.cnt.p; d.active = (int *)L.active_dev.p;
         d.carried = (int *)L.carried.p; d.reuse = 0;
         d.v2w[0] = d.v2w[1] = d.v2b[0] = d.v2b[1] = nullptr;
-        d.cache = nullptr; d.cache_mask = 0; d.cache_gen = e->cache_gen;
+        d.cache = nullptr; d.cache_mask = 0; d.cache_gen = e->cache_gen; d.ext_eval = 0;
         if (!rc) rc = alloc_items(e, L, 1);
     }
     if (!rc) rc = dev_alloc(e, e->next_game, 16);
@@ -1520,3 +1520,115 @@ extern "C" int az_set_eval_cache(az_engine *e, int64_t entries)
 }
 
 extern "C" int az_get_persistent(const az_engine *e) { return e ? e->persist_gp : AZ_ERR_INVALID; }
+
+// MCTS.run with the evaluator outside the engine: the policy_value_fn seam of mcts.py:87-93 for evaluators that are not
+// this engine's net (any callable in the reference).  The tree kernels run on the GPU as always; each of the
+// num_simulations + 1 evaluations crosses to the host: the pending leaf is read back, the callback fills priors and
+// value, they are uploaded, and the tree step consumes them as they are (no softmax, no value head).
+extern "C" int az_search_callback(az_engine *e, const uint8_t *board, int player, int last, double temperature,
+                                  const double *noise, double u, az_eval_callback fn, void *user, float *pi, int32_t *action,
+                                  int32_t *visits, double *W, float *prior)
+{
+    if (!e || !board || !fn || (player != 1 && player != 2)) return fail(e, AZ_ERR_INVALID, "az_search_callback: bad argument");
+    if (e->run.open) return fail(e, AZ_ERR_STATE, "az_search_callback: a self-play episode is open on this engine");
+    if (e->vl > 1 || e->reuse) return fail(e, AZ_ERR_INVALID, "az_search_callback: not combinable with virtual-loss batching or subtree reuse");
+    DEVICE_GUARD(e);
+    const int nn = e->nn, S = e->cfg.num_simulations;
+    int stones = 0;
+    for (int j = 0; j < nn; j++) {
+        if (board[j] > 2) return fail(e, AZ_ERR_INVALID, "az_search_callback: cell value %d", board[j]);
+        stones += board[j] != 0;
+    }
+    if (stones >= nn) return fail(e, AZ_ERR_INVALID, "az_search_callback: no legal action");
+    if (last >= nn || (last >= 0 && board[last] == 0)) return fail(e, AZ_ERR_INVALID, "az_search_callback: bad last action");
+    int rc = ensure_episode_buffers(e, 1, true);
+    if (rc) return rc;
+    std::vector<double> T(nn + 1, temperature);
+    if ((rc = upload_T(e, T.data(), false))) return rc;
+    std::vector<double> hn((size_t)e->tape_len, 0.0), hu(nn, u);
+    int off = 0;
+    for (int m = 0; m < stones; m++) off += nn - m;
+    if (noise) memcpy(hn.data() + off, noise, (size_t)(nn - stones) * 8);
+    HIPCHECK(e, az_memcpy(e->stream, e->noise.p, hn.data(), hn.size() * 8, hipMemcpyHostToDevice));
+    HIPCHECK(e, az_memcpy(e->stream, e->u.p, hu.data(), hu.size() * 8, hipMemcpyHostToDevice));
+    u64 bd[8];
+    planes_from_cells(board, nn, bd, bd + 4);
+    Lane &L = e->lanes[0];
+    HIPCHECK(e, hipMemsetAsync(L.s_status.p, 0, L.s_status.bytes, e->stream));
+    HIPCHECK(e, hipMemcpyAsync(L.board.p, bd, sizeof bd, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_set_position, dim3(1), dim3(64), 0, e->stream, L.d, 0, 0, player, last, stones);
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    // the episode machinery is bypassed: this loop is the episode (one game, one ply), driven step by step from the host
+    const bool had_cache = e->cache.p != nullptr;
+    each_state(e, [&](DevState &d) {
+        d.max_plies = 0; d.add_noise = noise ? 1 : 0; d.arena = 0; d.total_games = 1; d.reuse = 0;
+        d.cache = nullptr; d.ext_eval = 1;
+    });
+    HIPCHECK(e, hipMemsetAsync(L.cnt.p, 0, L.cnt.bytes, e->stream));
+    HIPCHECK(e, hipMemsetAsync(L.carried.p, 0xFF, L.carried.bytes, e->stream));
+    e->persist_gp = 0;
+    LaunchCtx lc = ctx_of_impl(e, L);
+    lc.synthetic = 0;
+    hipLaunchKernelGGL(k_begin, dim3((L.d.B + 255) / 256), dim3(256), 0, e->stream, L.d);
+    std::vector<float> pol(e->RW, 0.0f), hid(64, 0.0f);
+    std::vector<uint8_t> cells(nn);
+    int cbrc = 0;
+    for (int idx = 0; idx <= S && !rc; idx++) {
+        int kind = LEAF_NONE, depth = 0, llast = -1;
+        u64 lf[8];
+        hipError_t hr = az_memcpy(e->stream, &kind, L.leaf_kind.p, 4, hipMemcpyDeviceToHost);
+        if (hr == hipSuccess && leaf_needs_net(kind)) {
+            hr = az_memcpy(e->stream, lf, L.leaf.p, sizeof lf, hipMemcpyDeviceToHost);
+            if (hr == hipSuccess) hr = az_memcpy(e->stream, &depth, L.depth.p, 4, hipMemcpyDeviceToHost);
+            if (hr == hipSuccess) hr = az_memcpy(e->stream, &llast, L.leaf_last.p, 4, hipMemcpyDeviceToHost);
+            if (hr == hipSuccess) {
+                const int mover = (depth & 1) ? 3 - player : player;     // side to move at the leaf
+                for (int j = 0; j < nn; j++) {
+                    const bool me = (lf[j >> 6] >> (j & 63)) & 1ull, op = (lf[4 + (j >> 6)] >> (j & 63)) & 1ull;
+                    cells[j] = (uint8_t)(me ? mover : (op ? 3 - mover : 0));
+                }
+                float value = 0.0f;
+                std::fill(pol.begin(), pol.end(), 0.0f);
+                cbrc = fn(user, cells.data(), mover, llast, pol.data(), &value);
+                if (cbrc) { rc = fail(e, AZ_ERR_INVALID, "az_search_callback: the evaluator returned %d", cbrc); break; }
+                hid[0] = value;
+                hr = az_memcpy(e->stream, L.logits.p, pol.data(), (size_t)e->RW * 4, hipMemcpyHostToDevice);
+                if (hr == hipSuccess) hr = az_memcpy(e->stream, L.vhid.p, hid.data(), 64 * 4, hipMemcpyHostToDevice);
+            }
+        }
+        if (hr != hipSuccess) { rc = fail(e, AZ_ERR_HIP, "az_search_callback: %s", hipGetErrorString(hr)); break; }
+        e->ops->step(lc, idx, idx < S ? 1 : 0);
+    }
+    if (!rc) {
+        e->ops->move(lc);
+        hipError_t hr = hipStreamSynchronize(e->stream);
+        if (hr == hipSuccess) hr = hipGetLastError();
+        if (hr != hipSuccess) rc = fail(e, AZ_ERR_HIP, "az_search_callback: %s", hipGetErrorString(hr));
+    } else {
+        (void)hipStreamSynchronize(e->stream);
+    }
+    each_state(e, [&](DevState &d) { d.ext_eval = 0; d.cache = had_cache ? (float *)e->cache.p : nullptr; });
+    (void)hipMemsetAsync(L.s_status.p, 0, L.s_status.bytes, e->stream);
+    (void)hipMemsetAsync(L.leaf_kind.p, 0, L.leaf_kind.bytes, e->stream);
+    (void)hipStreamSynchronize(e->stream);
+    e->have_episode = false;
+    if (rc) return rc;
+    const size_t ri = (size_t)stones;
+    if (pi) HIPCHECK(e, az_memcpy(e->stream, pi, (float *)e->rec_pi.p + ri * nn, (size_t)nn * 4, hipMemcpyDeviceToHost));
+    if (action) {
+        short a = -1;
+        HIPCHECK(e, az_memcpy(e->stream, &a, (short *)e->rec_action.p + ri, 2, hipMemcpyDeviceToHost));
+        *action = a;
+    }
+    if (visits || W || prior) {
+        std::vector<Edge> row(e->RW);
+        HIPCHECK(e, az_memcpy(e->stream, row.data(), L.edges.p, row.size() * sizeof(Edge), hipMemcpyDeviceToHost));
+        for (int j = 0; j < nn; j++) {
+            const bool legal = board[j] == 0;
+            if (visits) visits[j] = legal ? row[j].N : 0;
+            if (W) W[j] = legal ? row[j].W : 0.0;
+            if (prior) prior[j] = legal ? row[j].P : 0.0f;
+        }
+    }
+    return AZ_OK;
+}

@@ -16,6 +16,10 @@
 #pragma once
 #include "az_net.h"
 
+#ifndef AZ_SEARCH_SKIP
+#define AZ_SEARCH_SKIP 0      // timing-only experiment builds (results are wrong): 1 = no FC, 2 = no tree step, 4 = no conv trunk
+#endif
+
 template <int N, int GP>
 struct PersistGeo {
     static constexpr int n = N, nn = N * N, PW = N + 2, PP = PW * PW;
@@ -180,36 +184,71 @@ __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edg
     }
 }
 
-// policy_fc (net.py:65) and value_fc1 + ReLU (net.py:69) of the workgroup's GP boards: one thread per output, one
-// k-ordered fmaf chain from +0, bias afterwards -- the chain v_mfma_f32_16x16x4_f32 runs in k_fc.  The weights are read
-// from the MFMA-fragment packing of az_engine.hip pack_fc: element (k, j) at ((tile*KS4PAD + k/16)*64 + (k%4)*16 + j%16)*4 + (k/4)%4.
+// policy_fc (net.py:65) and value_fc1 + ReLU (net.py:69) of the workgroup's GP boards: k_fc's MFMA chain (az_net.h) with
+// the board rows beyond GP supplied as zeros from registers -- one 16-output tile per wave, the weight fragments streamed
+// from L2 a whole chunk (32 MFMAs) ahead, the feature rows read from LDS.  featl rows have stride NG::FSTR with a zero
+// tail, which the padded k-steps of the last weight group read (times zero weights).
 template <class PG, class NG>
-__device__ __forceinline__ void fc_valu(const NetWeights &w, const float *featl, float *logits_l, float *vhid_l, int tid, int nthreads)
+__device__ __forceinline__ void fc_mfma(const NetWeights &w, const float *featl, float *logits_l, float *vhid_l, int wave, int lane)
 {
-    constexpr int nn = PG::nn, OUTS = nn + 64;
-    for (int o = tid; o < PG::G * OUTS; o += nthreads) {
-        const int g = o / OUTS, r = o - g * OUTS;
-        const bool pol = r < nn;
-        const int j = pol ? r : r - nn;
-        const int K = pol ? PG::PC * nn : PG::VC * nn;
-        const int ks4pad = pol ? NG::KS4P_PAD : NG::KS4V_PAD;
-        const float4 *wp = reinterpret_cast<const float4 *>(pol ? w.pf : w.vf) + (size_t)(j >> 4) * ks4pad * 64 + (j & 15);
-        const float *x = featl + g * PG::FROW + (pol ? 0 : PG::PC * nn);
-        float acc = 0.0f;
-        const int groups = (K + 15) / 16;
-        for (int s4 = 0; s4 < groups; s4++) {
-            const float4 w0 = wp[(size_t)s4 * 64 + 0], w1 = wp[(size_t)s4 * 64 + 16], w2 = wp[(size_t)s4 * 64 + 32], w3 = wp[(size_t)s4 * 64 + 48];
-            const float wk[16] = {w0.x, w1.x, w2.x, w3.x, w0.y, w1.y, w2.y, w3.y, w0.z, w1.z, w2.z, w3.z, w0.w, w1.w, w2.w, w3.w};
+    const int tile = wave;
+    if (tile >= NG::NTP + 4) return;
+    const int q = lane >> 4, r16 = lane & 15;
+    const bool is_pol = tile < NG::NTP;
+    const int KS = is_pol ? NG::KSP : NG::KSV;
+    const int KS4 = (KS + 3) / 4;
+    constexpr int CH = 8;                              // weight groups (of 4 k-steps) per chunk
+    const int NCH = (KS4 + CH - 1) / CH;               // the packed weights are zero-padded to whole chunks of 16 groups
+    const float4 *wp4 = reinterpret_cast<const float4 *>(is_pol ? w.pf : w.vf) +
+                        (size_t)(is_pol ? tile : tile - NG::NTP) * (is_pol ? NG::KS4P_PAD : NG::KS4V_PAD) * 64 + lane;
+    const bool row_ok = r16 < PG::G;
+    const float *ip = featl + (row_ok ? r16 : 0) * NG::FSTR + (is_pol ? 0 : NG::PC * NG::nn) + q;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 bcur[CH], bnxt[CH];
+    float acur[CH][4], anxt[CH][4];
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int k = 16 * s4 + i;                       // k = 16*s4 + 4*(s%4) + kk: ascending
-                if (k < K) acc = __builtin_fmaf(x[k], wk[i], acc);
-            }
+    for (int j = 0; j < CH; j++) {
+        bcur[j] = wp4[(size_t)j * 64];
+#pragma unroll
+        for (int e = 0; e < 4; e++) acur[j][e] = row_ok ? ip[j * 16 + e * 4] : 0.0f;
+    }
+    for (int c = 0; c < NCH; c++) {
+        const int cn = c + 1 < NCH ? c + 1 : c;
+        const float *ipn = ip + cn * CH * 16;
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            bnxt[j] = wp4[(size_t)(cn * CH + j) * 64];
+#pragma unroll
+            for (int e = 0; e < 4; e++) anxt[j][e] = row_ok ? ipn[j * 16 + e * 4] : 0.0f;
         }
-        if (pol) logits_l[g * PG::RW + j] = acc + w.pfb[j];
-        else {
-            const float v = acc + w.vfb[j];
-            vhid_l[g * 64 + j] = v > 0.0f ? v : 0.0f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            acc = mfma4(acur[j][0], bcur[j].x, acc);
+            acc = mfma4(acur[j][1], bcur[j].y, acc);
+            acc = mfma4(acur[j][2], bcur[j].z, acc);
+            acc = mfma4(acur[j][3], bcur[j].w, acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            bcur[j] = bnxt[j];
+#pragma unroll
+            for (int e = 0; e < 4; e++) acur[j][e] = anxt[j][e];
+        }
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+        const int g = q * 4 + rg;                      // board row of this accumulator register
+        if (g < PG::G) {
+            if (is_pol) {
+                const int j = tile * 16 + r16;
+                if (j < NG::nn) logits_l[g * PG::RW + j] = acc[rg] + w.pfb[j];
+            } else {
+                const int i = (tile - NG::NTP) * 16 + r16;
+                const float v = acc[rg] + w.vfb[i];
+                vhid_l[g * 64 + i] = v > 0.0f ? v : 0.0f;
+            }
         }
     }
 }
@@ -226,7 +265,7 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
     __shared__ __attribute__((aligned(16))) float lds[PG::LDSF];
     __shared__ unsigned short wpos[PG::MR];
     __shared__ unsigned short cellof[PG::MR];
-    __shared__ __attribute__((aligned(16))) float featl[GP * PG::FROW];
+    __shared__ __attribute__((aligned(16))) float featl[GP * NG::FSTR];       // head-conv outputs, rows zero beyond 6 n^2
     __shared__ float logits_l[GP * PG::RW];
     __shared__ float vhid_l[GP * 64];
     __shared__ unsigned path_l[GP][PG::PATH];
@@ -241,6 +280,7 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
     const int b0 = blockIdx.x * GP;
     const int S = d.S;
     for (int i = tid; i < S + 2; i += NTH) sq_lds[i] = d.sqrt_table[i];
+    for (int i = tid; i < GP * NG::FSTR; i += NTH) featl[i] = 0.0f;
     // tile tables (constant over the ply)
     for (int m = tid; m < PG::MR; m += NTH) {
         const int g = m / PG::nn, p = m - g * PG::nn, r = p / N, c = p - r * N;
@@ -304,6 +344,7 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
                 }
             }
             __syncthreads();
+            if (!(AZ_SEARCH_SKIP & 4)) {
             conv_layer<PG, 4, 32, CONV_OUT_PACKED>(inB, inA, w.c1, w.c1b, wpos, cellof, wave, lane);
             __syncthreads();
             for (int i = tid; i < 3 * PG::CS; i += NTH) inB[i] = 0.0f;
@@ -312,6 +353,7 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
             __syncthreads();
             conv_layer<PG, 64, 128, CONV_OUT3>(inB, lds, w.c3, w.c3b, wpos, cellof, wave, lane);
             __syncthreads();
+            }
             // policy_conv (128->4) and value_conv (128->2), 1x1, into the LDS feature rows
             {
                 const int q = lane >> 4, r16 = lane & 15;
@@ -338,18 +380,18 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
                             const int j = q * 4 + rg;     // head channel: 0-3 policy_conv, 4-5 value_conv (net.py:64,69 flatten order)
                             if (j < 6) {
                                 float v = acc[rg] + hb[rg];
-                                featl[g * PG::FROW + j * PG::nn + p] = v > 0.0f ? v : 0.0f;
+                                featl[g * NG::FSTR + j * PG::nn + p] = v > 0.0f ? v : 0.0f;
                             }
                         }
                     }
                 }
             }
             __syncthreads();
-            fc_valu<PG, NG>(w, featl, logits_l, vhid_l, tid, NTH);
+            if (!(AZ_SEARCH_SKIP & 1)) fc_mfma<PG, NG>(w, featl, logits_l, vhid_l, wave, lane);
             __syncthreads();
         }
         // ---- tree step: wave g works on game g ----
-        if (mine)
+        if (mine && (!(AZ_SEARCH_SKIP & 2) || idx == S))
             step_lds<N, PG, SYNTH>(d, gb, lane, rows_all + (size_t)wave * d.R * PG::ROWE, path_l[wave], games[wave],
                                    logits_l + wave * PG::RW, vhid_l + wave * 64, sq_lds, idx, idx < S ? 1 : 0, pl, slast, netid,
                                    game, ply, bX, bO, cnt);

@@ -78,6 +78,7 @@ struct DevState {
     // --- opt-in virtual-loss batching (the reference's TODO, mcts.py:17-22): L leaves per game and evaluation batch ---
     int L;                 // 1 = the reference's sequential simulation loop (mcts.py:123-141)
     int *it_status, *it_net;   // [B*L] per evaluation item, what the net kernels read as s_status / s_net (alias them when L == 1)
+    int ext_eval;          // the pending rows were filled by an evaluator outside the engine (az_search_callback): priors and value as given
 };
 
 template <int N>
@@ -323,8 +324,7 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
 #pragma unroll
         for (int i = 0; i < G::CPL; i++) x[i] = lg[lane + 64 * i];
         h_l = d.vhid[(size_t)bb * 64 + lane];
-        w2a = d.v2w[0][lane];
-        b2a = d.v2b[0][0];
+        if (d.v2w[0]) { w2a = d.v2w[0][lane]; b2a = d.v2b[0][0]; }
         if (d.v2w[1]) { w2b = d.v2w[1][lane]; b2b = d.v2b[1][0]; }
     }
     __syncthreads();
@@ -385,6 +385,13 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
                     for (int i = 0; i < G::CPL; i++) xc[i] = lane + 64 * i < G::nn ? x[i] : 0.0f;
                     cache_insert<N>(d, lme, lopp, leaf_last, netid, lane, xc, h_l);
                 }
+                if (d.ext_eval) {
+                    // the evaluator lives outside the engine (policy_value_fn seam, mcts.py:87-93,109,137): the row holds
+                    // the priors it returned, as they are, and the first hidden entry its value
+#pragma unroll
+                    for (int i = 0; i < G::CPL; i++) P[i] = lane + 64 * i < G::nn ? x[i] : 0.0f;
+                    v = __shfl(h_l, 0, 64);
+                } else {
                 // controller.py:49 softmax over all n^2 logits (no legality mask), canonical wave order
                 float mx = -INFINITY;
 #pragma unroll
@@ -411,6 +418,7 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
 #pragma unroll
                 for (int i = 0; i < 64; i++) acc = __builtin_fmaf(__shfl(h_l, i, 64), __shfl(w2_l, i, 64), acc);
                 v = az_tanhf(acc + (netid ? b2b : b2a));
+                }
             }
             if (kind == LEAF_ROOT && d.add_noise) {
                 // mcts.py:113-116; float32 multiply, float64 add, float32 store

@@ -18,10 +18,12 @@ def numpy_log_table(S):
 
 class MCTS:
     def __init__(self, policy_value_fn, num_simulations, c_puct, dirichlet_alpha=0.3, dirichlet_weight=0.25, virtual_loss=1):
-        if not isinstance(policy_value_fn, PolicyValueFn):
-            raise NotImplementedError(
-                "the GPU search evaluates leaves inside the HIP engine; pass make_policy_value_fn(controller) "
-                "(arbitrary Python callables would need a per-leaf host round trip and are not supported)")
+        if not callable(policy_value_fn):
+            raise TypeError("policy_value_fn must be callable: state -> (policy [n, n], value)")
+        # make_policy_value_fn(controller): the leaves are evaluated inside the HIP engine.  Any other callable keeps the
+        # reference's plugin seam (mcts.py:87-93): the tree stays on the GPU and every evaluation is one host round trip
+        # (az_search_callback) -- compatible, not fast.
+        self._external = not isinstance(policy_value_fn, PolicyValueFn)
         self.policy_value_fn = policy_value_fn
         self.num_simulations = num_simulations
         self.c_puct = c_puct
@@ -30,6 +32,26 @@ class MCTS:
         self.virtual_loss = virtual_loss      # opt-in: leaves per evaluation batch (az_set_virtual_loss); 1 = the reference's loop
         self._engine = None
         self._version = None
+
+    def _eng_external(self, n, k):
+        if self._engine is None or (self._engine.n, self._engine.k) != (n, k):
+            self._engine = Engine(n, k, self.num_simulations, 1, c_puct=self.c_puct, dirichlet_alpha=self.dirichlet_alpha,
+                                  dirichlet_weight=self.dirichlet_weight, log_table=numpy_log_table(self.num_simulations))
+        return self._engine
+
+    def _run_external(self, root_state, temperature, noise, u):
+        from .games import Gomoku
+        n, k = root_state.board_size, root_state.win_length
+
+        def evaluate(cells, player, last):
+            g = Gomoku(n, k)
+            g.cells = cells
+            g.current_player = _c.X if player == 1 else _c.O
+            g.last_action = None if last < 0 else (last // n, last % n)
+            return self.policy_value_fn(g)
+
+        return self._eng_external(n, k).search_callback(root_state.cells, root_state.player_code(), root_state.last_index(),
+                                                        float(temperature), evaluate, noise, u)
 
     def _eng(self, n, k):
         ctrl = self.policy_value_fn.controller
@@ -48,13 +70,16 @@ class MCTS:
 
     def run(self, root_state, temperature, add_root_noise=False):
         n = root_state.board_size
-        eng = self._eng(n, root_state.win_length)
         legal = int((root_state.cells == 0).sum())
         if legal == 0:
             return np.zeros((n, n), dtype=np.float32), None            # mcts.py:152-153
         noise = np.random.dirichlet([self.dirichlet_alpha] * legal) if add_root_noise else None
         u = np.random.random_sample()
-        r = eng.search(root_state.cells, root_state.player_code(), root_state.last_index(), float(temperature), noise, u)
+        if self._external:
+            r = self._run_external(root_state, temperature, noise, u)
+        else:
+            eng = self._eng(n, root_state.win_length)
+            r = eng.search(root_state.cells, root_state.player_code(), root_state.last_index(), float(temperature), noise, u)
         a = r["action"]
         self.last_visits = r["N"].reshape(n, n)
         return r["pi"].reshape(n, n), (a // n, a % n)

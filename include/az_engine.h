@@ -107,6 +107,20 @@ int az_search(az_engine *e, int slot, const uint8_t *board, int player, int last
               const double *noise, double u, float *pi, int32_t *action, int32_t *visits, double *W,
               float *prior);
 
+/* ---- the same search with the evaluator outside the engine: the policy_value_fn plugin seam (mcts.py:87-93) ----
+ * The reference's MCTS takes ANY callable state -> (policy float32[n,n], value float) (controller.py:39-53 is just the
+ * one the training loop uses).  az_search_callback keeps that seam: select / expand / backup / pi extraction run on the
+ * GPU as in az_search, and each of the num_simulations + 1 evaluations (mcts.py:109,137) is handed to `fn` on the host:
+ * board[n*n] absolute cells (0 empty, 1 X, 2 O), player = side to move there, last = last action (-1 none); fn writes
+ * policy[n*n] (used as priors exactly as given: mcts.py:63 float(policy[r, c]), no masking, no renormalisation) and
+ * *value (from the point of view of `player`), and returns 0 (anything else aborts the search with AZ_ERR_INVALID).
+ * One host round trip per simulation: a compatibility path, not a fast one.  Needs no weights; not combinable with
+ * virtual-loss batching or subtree reuse.  Other arguments and outputs as az_search. */
+typedef int (*az_eval_callback)(void *user, const uint8_t *board, int player, int last, float *policy, float *value);
+int az_search_callback(az_engine *e, const uint8_t *board, int player, int last, double temperature, const double *noise,
+                       double u, az_eval_callback fn, void *user, float *pi, int32_t *action, int32_t *visits, double *W,
+                       float *prior);
+
 /* ---- self-play episode: SelfPlayManager.generate_self_play + _worker (self_play.py:29-77,110-159) ----
  * Plays games with ids [0, num_games); game g draws its randomness from numpy-compatible
  * RandomState(seed0 + g) (dirichlet then one uniform per ply) unless a tape is given.
