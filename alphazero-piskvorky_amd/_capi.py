@@ -23,11 +23,13 @@ AZ_EVAL_NET, AZ_EVAL_SYNTHETIC = 0, 1
 AZ_RES_NONE, AZ_RES_X, AZ_RES_O, AZ_RES_DRAW = 0, 1, 2, 3
 AZ_AUG_NONE, AZ_AUG_REFERENCE4, AZ_AUG_DIHEDRAL8 = 1, 4, 8
 AZ_MODEL_PLAIN, AZ_MODEL_RESNET = 0, 1
+AZ_TRUNK_F32, AZ_TRUNK_BF16X3 = 0, 1
 
 EXPORTS = [
     "az_create", "az_destroy", "az_last_error", "az_load_weights", "az_load_weights_resnet", "az_net_eval", "az_search", "az_search_callback", "az_selfplay",
     "az_selfplay_begin", "az_selfplay_step", "az_selfplay_end", "az_selfplay_games", "az_selfplay_records", "az_record_bytes", "az_selfplay_pack", "az_examples_from_packed",
     "az_examples_gather", "az_arena", "az_rules_replay", "az_rng_selfplay_tape", "az_rng_uniforms", "az_set_profiling", "az_set_subtree_reuse", "az_get_counters", "az_get_lanes", "az_get_persistent", "az_set_virtual_loss", "az_set_eval_cache",
+    "az_set_trunk_mode", "az_get_trunk_mode",
 ]
 
 
@@ -370,6 +372,15 @@ class Engine:
     def set_eval_cache(self, entries):
         """Opt-in: evaluation cache of `entries` positions in HBM (mcts.py:17,22 TODO), 0 = off; results are bit-identical."""
         self._check(lib().az_set_eval_cache(self.h, C.c_int64(int(entries))), "az_set_eval_cache")
+
+    def set_trunk_mode(self, mode):
+        """Opt-in: "bf16x3" = fp32-emulating conv trunk on the bf16 matrix cores (tolerance instead of bit-exactness),
+        "f32" = the default canonical float32 trunk.  See include/az_engine.h."""
+        code = {"f32": AZ_TRUNK_F32, "bf16x3": AZ_TRUNK_BF16X3}.get(mode, mode)
+        self._check(lib().az_set_trunk_mode(self.h, int(code)), "az_set_trunk_mode")
+
+    def trunk_mode(self):
+        return "bf16x3" if int(lib().az_get_trunk_mode(self.h)) == AZ_TRUNK_BF16X3 else "f32"
 
     def set_profiling(self, on):
         lib().az_set_profiling(self.h, 1 if on else 0)

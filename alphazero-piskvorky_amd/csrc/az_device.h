@@ -196,3 +196,28 @@ __device__ __forceinline__ bool wins_through(const Plane &me, int a, int n, int 
     }
     return win;
 }
+
+// The same test done by the 64 lanes of a wavefront together (every lane must be active and hold the same plane and a):
+// lane = 16 * direction + 8 * side + (s - 1) probes the cell s steps from a along that direction and side; one ballot
+// gathers the 64 probes, and the run through a is counted with count-trailing-zero on the inverted 8-bit groups.  Replaces
+// up to 8 (k - 1) dependent scalar probes on the selection's latency chain.  Falls back to the loop for k > 9.
+__device__ __forceinline__ bool wins_through_wave(const Plane &me, int a, int n, int k, int lane)
+{
+    if (k > 9) return wins_through(me, a, n, k);
+    const int r = a / n, c = a - r * n;
+    const int dsel = lane >> 4, s = (lane & 7) + 1, sgn = (lane & 8) ? -s : s;
+    const int dr = dsel == 0 ? 0 : 1, dc = dsel == 0 ? 1 : (dsel == 1 ? 0 : (dsel == 2 ? 1 : -1));
+    const int rr = r + sgn * dr, cc = c + sgn * dc;
+    const bool inb = s < k && rr >= 0 && rr < n && cc >= 0 && cc < n;
+    const bool stone = inb && pl_get(me, inb ? rr * n + cc : 0);
+    const u64 m = __ballot(stone);
+    bool win = false;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const unsigned g = (unsigned)(m >> (16 * d)) & 0xFFFFu;
+        const int fwd = __builtin_ctz(~(g & 0xFFu) | 0x100u);          // consecutive stones on the + side (0..8)
+        const int bwd = __builtin_ctz(~((g >> 8) & 0xFFu) | 0x100u);   // ... and on the - side
+        win = win || (1 + fwd + bwd >= k);
+    }
+    return win;
+}

@@ -33,6 +33,7 @@ struct PackedNet {
     bool loaded = false;
     DevBuf c1, c2, c3, hd, pf, vf, c1b, c2b, c3b, hdb, pfb, vfb, v2w, v2b;
     DevBuf rblk[6], rblkb[6];          // ResidualBlock variant: the six 64->64 convs (c1/c1b hold the stem)
+    DevBuf c2x, c3x;                   // conv2 / conv3 split three ways into bf16 MFMA fragments (az_net_bf3.h)
     NetWeights w{};
     ResWeights rw{};
 };
@@ -81,6 +82,7 @@ struct az_engine {
     int vl = 1;                    // leaves per game and evaluation batch (az_set_virtual_loss); 1 = the reference's sequential loop
     bool vl_kernel = false;        // the batched tree kernel is in use (vl > 1, or AZ_VL_FORCE=1 to run it with batches of one)
     bool persist_allowed = true;   // AZ_PERSIST=0: never use the persistent search kernel
+    int trunk_mode = AZ_TRUNK_F32; // az_set_trunk_mode: AZ_TRUNK_BF16X3 = conv2 / conv3 on the bf16 MFMA, three-way split operands
     int persist_gp = 0;            // games per workgroup of the persistent search kernel for the open episode, 0 = lock-step pipeline
     DevBuf cache;                  // evaluation cache shared by the lanes (az_set_eval_cache)
     unsigned cache_mask = 0, cache_gen = 1;
@@ -118,6 +120,7 @@ static LaunchCtx ctx_of_impl(const az_engine *e, const Lane &L)
     c.synthetic = e->cfg.eval_kind == AZ_EVAL_SYNTHETIC;
     c.persist_gp = e->persist_gp;
     c.vl_kernel = e->vl_kernel ? 1 : 0;
+    c.emul = e->trunk_mode == AZ_TRUNK_BF16X3 ? 1 : 0;
     c.feat = (float *)L.pol_feat.p;
     c.dbg = (unsigned long long *)L.dbg.p;
     c.scratch = (float *)L.scratch.p;
@@ -219,6 +222,43 @@ static std::vector<float> pack_conv(const float *w, int cout, int cin)
                 int ci = 4 * sp + (lane >> 4), co = t * 16 + (lane & 15);
                 out[(((size_t)t * ks4 + s / 4) * 64 + lane) * 4 + (s % 4)] = w[((size_t)co * cin + ci) * 9 + tap];
             }
+    return out;
+}
+// fp32-emulating trunk (az_net_bf3.h): A-operand fragments of v_mfma_f32_16x16x32_bf16 with every weight split three
+// ways, w = hi + mid + lo (each the round-to-nearest-even bf16 of what the previous parts left over).  Lane l supplies
+// A[row = l & 15][k = 8 (l >> 4) + j]; K-block kb = one tap x 32 input channels:
+//   packed[(((ntile * KB + kb) * 3 + split) * 64 + lane) * 8 + j]
+static inline uint16_t bf16_rne(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_val(uint16_t h)
+{
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static std::vector<uint16_t> pack_conv_bf3(const float *w, int cout, int cin)
+{
+    const int kbt = cin / 32, kb_n = 9 * kbt, nt = cout / 16;
+    std::vector<uint16_t> out((size_t)nt * kb_n * 3 * 64 * 8, 0);
+    for (int t = 0; t < nt; t++)
+        for (int kb = 0; kb < kb_n; kb++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const int tap = kb / kbt, ci = (kb % kbt) * 32 + 8 * (lane >> 4) + j, co = t * 16 + (lane & 15);
+                    const float x = w[((size_t)co * cin + ci) * 9 + tap];
+                    const uint16_t hi = bf16_rne(x);
+                    const float r1 = x - bf16_val(hi);
+                    const uint16_t mid = bf16_rne(r1);
+                    const uint16_t lo = bf16_rne(r1 - bf16_val(mid));
+                    const size_t base = (((size_t)t * kb_n + kb) * 3 * 64 + lane) * 8 + j;
+                    out[base] = hi; out[base + 64 * 8] = mid; out[base + 2 * 64 * 8] = lo;
+                }
     return out;
 }
 static std::vector<float> pack_heads(const float *pw, int pc, const float *vw, int vc, int cin)
@@ -583,7 +623,7 @@ extern "C" void az_destroy(az_engine *e)
     for (DevBuf *b : shared) dev_free(*b);
     for (int s = 0; s < 2; s++) {
         PackedNet &p = e->net[s];
-        DevBuf *nb[] = {&p.c1, &p.c2, &p.c3, &p.hd, &p.pf, &p.vf, &p.c1b, &p.c2b, &p.c3b, &p.hdb, &p.pfb, &p.vfb, &p.v2w, &p.v2b};
+        DevBuf *nb[] = {&p.c1, &p.c2, &p.c3, &p.hd, &p.pf, &p.vf, &p.c1b, &p.c2b, &p.c3b, &p.hdb, &p.pfb, &p.vfb, &p.v2w, &p.v2b, &p.c2x, &p.c3x};
         for (DevBuf *b : nb) dev_free(*b);
         for (int i = 0; i < 6; i++) { dev_free(p.rblk[i]); dev_free(p.rblkb[i]); }
     }
@@ -607,6 +647,11 @@ extern "C" int az_load_weights(az_engine *e, int slot, const float *const *t)
     up(p.c1, pack_conv(t[0], 32, 4));   upraw(p.c1b, t[1], 32);
     up(p.c2, pack_conv(t[2], 64, 32));  upraw(p.c2b, t[3], 64);
     up(p.c3, pack_conv(t[4], 128, 64)); upraw(p.c3b, t[5], 128);
+    {
+        const std::vector<uint16_t> x2 = pack_conv_bf3(t[2], 64, 32), x3 = pack_conv_bf3(t[4], 128, 64);
+        if (!rc) rc = upload(e, p.c2x, x2.data(), x2.size() * 2);
+        if (!rc) rc = upload(e, p.c3x, x3.data(), x3.size() * 2);
+    }
     up(p.hd, pack_heads(t[6], 4, t[10], 2, 128));
     float hb[6] = {t[7][0], t[7][1], t[7][2], t[7][3], t[11][0], t[11][1]};
     upraw(p.hdb, hb, 6);
@@ -618,6 +663,7 @@ extern "C" int az_load_weights(az_engine *e, int slot, const float *const *t)
     p.w.hd = (const float *)p.hd.p; p.w.pf = (const float *)p.pf.p; p.w.vf = (const float *)p.vf.p;
     p.w.c1b = (const float *)p.c1b.p; p.w.c2b = (const float *)p.c2b.p; p.w.c3b = (const float *)p.c3b.p;
     p.w.hdb = (const float *)p.hdb.p; p.w.pfb = (const float *)p.pfb.p; p.w.vfb = (const float *)p.vfb.p;
+    p.w.c2x = p.c2x.p; p.w.c3x = p.c3x.p;
     e->cache_gen++;           // evaluations cached under the previous weights never match again
     each_state(e, [&](DevState &d) { d.v2w[slot] = (const float *)p.v2w.p; d.v2b[slot] = (const float *)p.v2b.p; d.cache_gen = e->cache_gen; });
     p.loaded = true;
@@ -730,7 +776,7 @@ static int episode_begin(az_engine *e, const EpisodeSpec &sp)
     });
     // persistent search kernel: plain net or synthetic evaluator, the reference's sequential search, trees that fit into LDS
     e->persist_gp = 0;
-    if (e->persist_allowed && e->cfg.model == AZ_MODEL_PLAIN && !e->vl_kernel && !e->reuse && !e->cache.p) {
+    if (e->persist_allowed && e->cfg.model == AZ_MODEL_PLAIN && !e->vl_kernel && !e->reuse && !e->cache.p && e->trunk_mode == AZ_TRUNK_F32) {
         const int synth = e->cfg.eval_kind == AZ_EVAL_SYNTHETIC ? 1 : 0;
         const int S = e->cfg.num_simulations;
         if (!sp.arena && !sp.preset && e->ops->search_prepare(S, 2, synth)) e->persist_gp = 2;
@@ -847,7 +893,8 @@ static int lane_plies(az_engine *e, Lane &L, int max_steps)
     const char *skip = getenv("AZ_DIAG_SKIP");
     const bool skip_fc = skip && strstr(skip, "fc"), skip_step = skip && strstr(skip, "step");
     for (int step = 0; step < max_steps && L.active > 0; step++) {
-        const bool use_split = e->split_max > 0 && L.scratch.p && L.active * e->vl <= e->split_max;   // few pending boards: latency path
+        // few pending boards: latency path (the emulated trunk has one kernel, so that its results never depend on the slot count)
+        const bool use_split = e->split_max > 0 && L.scratch.p && L.active * e->vl <= e->split_max && e->trunk_mode == AZ_TRUNK_F32;
         if (e->tapes) {       // the tapes of this ply must be on the device (streamed a wave ahead of the games)
             hipEvent_t ev = nullptr;
             hipError_t trc = e->tapes->need(L.plies_played, &ev);
@@ -1258,7 +1305,7 @@ extern "C" int az_net_eval(az_engine *e, int slot, int count, const uint8_t *boa
         if (hr != hipSuccess) { rc = fail(e, AZ_ERR_HIP, "az_net_eval upload: %s", hipGetErrorString(hr)); break; }
         {
             const LaunchCtx lc = ctx_of_impl(e, L);
-            if (e->split_max > 0 && L.scratch.p && cnt <= e->split_max) e->ops->trunk_split(lc, slot); else e->ops->trunk(lc, slot);
+            if (e->split_max > 0 && L.scratch.p && cnt <= e->split_max && e->trunk_mode == AZ_TRUNK_F32) e->ops->trunk_split(lc, slot); else e->ops->trunk(lc, slot);
             e->ops->fc(lc, slot);
             e->ops->eval_tail(lc, cnt, (float *)dpol.p, (float *)dval.p);
         }
@@ -1518,6 +1565,23 @@ extern "C" int az_set_eval_cache(az_engine *e, int64_t entries)
     each_state(e, [&](DevState &d) { d.cache = (float *)e->cache.p; d.cache_mask = e->cache_mask; d.cache_gen = e->cache_gen; });
     return AZ_OK;
 }
+
+extern "C" int az_set_trunk_mode(az_engine *e, int mode)
+{
+    if (!e) return AZ_ERR_INVALID;
+    if (e->run.open) return fail(e, AZ_ERR_STATE, "az_set_trunk_mode: an episode is open");
+    if (mode != AZ_TRUNK_F32 && mode != AZ_TRUNK_BF16X3) return fail(e, AZ_ERR_INVALID, "az_set_trunk_mode: unknown mode %d", mode);
+    if (mode == AZ_TRUNK_BF16X3 && e->cfg.model != AZ_MODEL_PLAIN)
+        return fail(e, AZ_ERR_INVALID, "az_set_trunk_mode: the fp32-emulating trunk exists for GomokuNet (AZ_MODEL_PLAIN) only");
+    if (mode != e->trunk_mode) {
+        e->trunk_mode = mode;
+        e->cache_gen++;           // cached evaluations of the other arithmetic never match again
+        each_state(e, [&](DevState &d) { d.cache_gen = e->cache_gen; });
+    }
+    return AZ_OK;
+}
+
+extern "C" int az_get_trunk_mode(const az_engine *e) { return e ? e->trunk_mode : AZ_ERR_INVALID; }
 
 extern "C" int az_get_persistent(const az_engine *e) { return e ? e->persist_gp : AZ_ERR_INVALID; }
 

@@ -169,7 +169,7 @@ __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edg
         pl_set(me, a);                                        // games.py:79-81 place, flip player, remember action
         Plane t = me; me = opp; opp = t;
         last = a;
-        if (wins_through(opp, a, N, d.k)) { out_kind = LEAF_TERM_LOSS; break; }  // the side to move has lost
+        if (wins_through_wave(opp, a, N, d.k, lane)) { out_kind = LEAF_TERM_LOSS; break; }  // the side to move has lost
         if (pl_count(me) + pl_count(opp) == G::nn) { out_kind = LEAF_TERM_DRAW; break; }
         if (child == 0) { out_kind = LEAF_EXPAND; break; }    // mcts.py:127 node.is_leaf()
         npar = an;

@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
         pl_set(me, a);                                        // games.py:79-81 place, flip player, remember action
         Plane t = me; me = opp; opp = t;
         last = a;
-        if (wins_through(opp, a, N, d.k)) { out_kind = LEAF_TERM_LOSS; break; }  // the side to move has lost
+        if (wins_through_wave(opp, a, N, d.k, lane)) { out_kind = LEAF_TERM_LOSS; break; }  // the side to move has lost
         if (pl_count(me) + pl_count(opp) == G::nn) { out_kind = LEAF_TERM_DRAW; break; }
         if (child == 0) { out_kind = LEAF_EXPAND; break; }    // mcts.py:127 node.is_leaf()
         npar = an;
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(256) void k_step_vl(DevState d, int sims_done, int 
             pl_set(me, a);                                        // games.py:79-81 place, flip player, remember action
             Plane t = me; me = opp; opp = t;
             last = a;
-            if (wins_through(opp, a, N, d.k)) { out_kind = LEAF_TERM_LOSS; break; }
+            if (wins_through_wave(opp, a, N, d.k, lane)) { out_kind = LEAF_TERM_LOSS; break; }
             if (pl_count(me) + pl_count(opp) == G::nn) { out_kind = LEAF_TERM_DRAW; break; }
             if (child == 0) { out_kind = LEAF_EXPAND; break; }    // mcts.py:127 node.is_leaf()
             npar = an;

@@ -44,6 +44,7 @@ typedef enum {
 enum { AZ_EVAL_NET = 0, AZ_EVAL_SYNTHETIC = 1 };   /* synthetic = deterministic hash evaluator (test hook, mcts.py:87-93 seam) */
 enum { AZ_RES_NONE = 0, AZ_RES_X = 1, AZ_RES_O = 2, AZ_RES_DRAW = 3 }; /* constants.py:11-13 'X','O','D' */
 enum { AZ_AUG_REFERENCE4 = 4, AZ_AUG_DIHEDRAL8 = 8, AZ_AUG_NONE = 1 };
+enum { AZ_TRUNK_F32 = 0, AZ_TRUNK_BF16X3 = 1 };   /* arithmetic of the conv trunk, az_set_trunk_mode */
 enum { AZ_MODEL_PLAIN = 0, AZ_MODEL_RESNET = 1 };  /* net.py GomokuNet | ResidualBlock variant (README.md:72) */
 
 /* Hyper-parameters the reference keeps in constants.py / MCTS.__init__ (mcts.py:87-97). */
@@ -261,6 +262,17 @@ int az_set_virtual_loss(az_engine *e, int leaves);
  * it.  entries = 0 switches it off (and frees it); otherwise rounded up to a power of two, (96 + roundup(n*n, 64)) * 4
  * bytes each.  Hits are reported in az_counters.cache_lookups / cache_hits.  Not allowed while an episode is open. */
 int az_set_eval_cache(az_engine *e, int64_t entries);
+
+/* Opt-in: fp32-emulating conv trunk.  AZ_TRUNK_F32 (default) computes GomokuNet.forward (net.py:55-72) on the float32
+ * matrix instruction in the build's canonical fp order: bit-identical to the oracle.  AZ_TRUNK_BF16X3 runs conv2 and conv3
+ * (99 % of the net's arithmetic) on the 16 x faster bf16 matrix instruction with every operand split into three bf16 parts
+ * and the six largest cross products accumulated in float32: float32-like accuracy (|logit| 2e-5, |P| 1e-6, |value| 2e-6
+ * against the oracle, the tolerances already granted against the Python reference's torch numbers), NOT bit-identical, so
+ * visit counts can differ from the reference's on near-tied PUCT scores.  One kernel for every occupancy (no split /
+ * persistent variants), so results do not depend on the slot count.  GomokuNet only.  Invalidates the evaluation cache.
+ * Not allowed while an episode is open. */
+int az_set_trunk_mode(az_engine *e, int mode);
+int az_get_trunk_mode(const az_engine *e);
 
 /* HIP-event timing of every trunk / FC / tree-step launch (az_counters.trunk_seconds, nn_seconds, step_seconds);
  * off by default: four events per evaluation batch cost a few microseconds of stream time, which matters on small boards.
