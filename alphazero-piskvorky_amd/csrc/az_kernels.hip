@@ -21,7 +21,7 @@ void trunk(const LaunchCtx &c, int net_id)
         typedef NetGeo<N> G;
         const int ngroups = (c.dv.B + G::G - 1) / G::G;
         if (c.emul) {
-            hipLaunchKernelGGL(k_trunk_bf3<N>, dim3(ngroups), dim3(G::NW * 64), 0, c.stream, c.dv, c.w[net_id], net_id, c.feat);
+            hipLaunchKernelGGL(k_trunk_bf3<N>, dim3(ngroups), dim3(G::NW * 64), 0, c.stream, c.dv, c.w[net_id], net_id, c.feat, c.dbg);
             return;
         }
         dim3 gt(AZ_SEQ == 0 ? (ngroups < 256 ? ngroups : 256) : (ngroups + AZ_SEQ - 1) / AZ_SEQ), bt(G::NW * 64);

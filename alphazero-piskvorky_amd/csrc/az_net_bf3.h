@@ -157,7 +157,8 @@ __device__ __forceinline__ void conv_layer_bf3(const uint4 *in, void *out, const
 }
 
 template <int N>
-__global__ __launch_bounds__(AZ_NW * 64) void k_trunk_bf3(DevState d, NetWeights w, int net_id, float *__restrict__ feat)
+__global__ __launch_bounds__(AZ_NW * 64) void k_trunk_bf3(DevState d, NetWeights w, int net_id, float *__restrict__ feat,
+                                                          unsigned long long *dbg)
 {
     typedef NetGeo<N> G;
     constexpr int NTH = AZ_NW * 64;
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk_bf3(DevState d, NetWeights
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = blockIdx.x, b0 = grp * G::G;
+    AZ_STAMP(0);
     if (tid == 0) any_active = 0;
     __syncthreads();
     if (tid < G::G) {
@@ -216,14 +218,19 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk_bf3(DevState d, NetWeights
         }
     }
     __syncthreads();
+    AZ_STAMP(1);
     conv_layer<G, 4, 32, CONV_OUT_BF3>(inP, lds, w.c1, w.c1b, wpos, cellof, wave, lane);
     __syncthreads();
     for (int i = tid; i < 3 * G::CS; i += NTH) inP[i] = 0.0f;      // plane 12 is part of conv2's output image
+    AZ_STAMP(2);
     conv_layer_bf3<G, 32, 64, BF3_OUT_IMAGE, 1>(reinterpret_cast<const uint4 *>(lds), lds, reinterpret_cast<const uint4 *>(w.c2x),
                                                 w.c2b, wpos, cellof, wave, lane);
     __syncthreads();
+    AZ_STAMP(3);
     conv_layer_bf3<G, 64, 128, BF3_OUT3, AZ_BF3_NTW>(reinterpret_cast<const uint4 *>(lds), lds, reinterpret_cast<const uint4 *>(w.c3x),
                                                      w.c3b, wpos, cellof, wave, lane);
     __syncthreads();
+    AZ_STAMP(4);
     trunk_heads<G>(d, w, net_id, feat, lds, cellof, b0, wave, lane);
+    AZ_STAMP(5);
 }

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: phase breakdown of k_trunk from s_memtime stamps (build with `make EXTRA=-DAZ_STAMPS`)."""
+"""Diagnostic: phase breakdown of k_trunk / k_trunk_bf3 from s_memtime stamps (build with `make EXTRA=-DAZ_STAMPS`):
+python tools/stamps.py [board] [f32|bf16x3]"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,6 +10,8 @@ from alphazero_piskvorky_amd.weights import synthetic_state_dict
 n, B = int(sys.argv[1]) if len(sys.argv) > 1 else 15, 1024
 e = az.Engine(n, 5 if n > 5 else 4, 8, B)
 e.load_weights(synthetic_state_dict(n), 0)
+if len(sys.argv) > 2:
+    e.set_trunk_mode(sys.argv[2])
 e.selfplay_begin(B, seed0=1)
 e.selfplay_step(1)
 G = {15: 1, 9: 2, 5: 4}[n]
