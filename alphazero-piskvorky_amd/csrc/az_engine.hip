@@ -33,7 +33,7 @@ struct PackedNet {
     bool loaded = false;
     DevBuf c1, c2, c3, hd, pf, vf, c1b, c2b, c3b, hdb, pfb, vfb, v2w, v2b;
     DevBuf rblk[6], rblkb[6];          // ResidualBlock variant: the six 64->64 convs (c1/c1b hold the stem)
-    DevBuf c2x, c3x;                   // conv2 / conv3 split three ways into bf16 MFMA fragments (az_net_bf3.h)
+    DevBuf c2x, c3x, hdx;              // conv2 / conv3 / head convs split three ways into bf16 MFMA fragments (az_net_bf3.h)
     NetWeights w{};
     ResWeights rw{};
 };
@@ -259,6 +259,27 @@ static std::vector<uint16_t> pack_conv_bf3(const float *w, int cout, int cin)
                     const size_t base = (((size_t)t * kb_n + kb) * 3 * 64 + lane) * 8 + j;
                     out[base] = hi; out[base + 64 * 8] = mid; out[base + 2 * 64 * 8] = lo;
                 }
+    return out;
+}
+// The 1x1 head convs for the fused epilogue of the emulated conv3: A-operand fragments of v_mfma_f32_16x16x16_bf16, one per
+// 16-channel tile of the conv3 output; lane l supplies A[row = l & 15 = head channel][k = 4 (l >> 4) + j] = w[row][16 tile + k]:
+//   packed[((tile * 3 + split) * 64 + lane) * 4 + j]
+static std::vector<uint16_t> pack_heads_bf3(const float *pw, int pc, const float *vw, int vc, int cin)
+{
+    const int nt = cin / 16;
+    std::vector<uint16_t> out((size_t)nt * 3 * 64 * 4, 0);
+    for (int t = 0; t < nt; t++)
+        for (int lane = 0; lane < 64; lane++)
+            for (int j = 0; j < 4; j++) {
+                const int row = lane & 15, ci = 16 * t + 4 * (lane >> 4) + j;
+                const float x = row < pc ? pw[row * cin + ci] : (row < pc + vc ? vw[(row - pc) * cin + ci] : 0.0f);
+                const uint16_t hi = bf16_rne(x);
+                const float r1 = x - bf16_val(hi);
+                const uint16_t mid = bf16_rne(r1);
+                const uint16_t lo = bf16_rne(r1 - bf16_val(mid));
+                const size_t base = ((size_t)t * 3 * 64 + lane) * 4 + j;
+                out[base] = hi; out[base + 64 * 4] = mid; out[base + 2 * 64 * 4] = lo;
+            }
     return out;
 }
 static std::vector<float> pack_heads(const float *pw, int pc, const float *vw, int vc, int cin)
@@ -623,7 +644,7 @@ extern "C" void az_destroy(az_engine *e)
     for (DevBuf *b : shared) dev_free(*b);
     for (int s = 0; s < 2; s++) {
         PackedNet &p = e->net[s];
-        DevBuf *nb[] = {&p.c1, &p.c2, &p.c3, &p.hd, &p.pf, &p.vf, &p.c1b, &p.c2b, &p.c3b, &p.hdb, &p.pfb, &p.vfb, &p.v2w, &p.v2b, &p.c2x, &p.c3x};
+        DevBuf *nb[] = {&p.c1, &p.c2, &p.c3, &p.hd, &p.pf, &p.vf, &p.c1b, &p.c2b, &p.c3b, &p.hdb, &p.pfb, &p.vfb, &p.v2w, &p.v2b, &p.c2x, &p.c3x, &p.hdx};
         for (DevBuf *b : nb) dev_free(*b);
         for (int i = 0; i < 6; i++) { dev_free(p.rblk[i]); dev_free(p.rblkb[i]); }
     }
@@ -651,6 +672,8 @@ extern "C" int az_load_weights(az_engine *e, int slot, const float *const *t)
         const std::vector<uint16_t> x2 = pack_conv_bf3(t[2], 64, 32), x3 = pack_conv_bf3(t[4], 128, 64);
         if (!rc) rc = upload(e, p.c2x, x2.data(), x2.size() * 2);
         if (!rc) rc = upload(e, p.c3x, x3.data(), x3.size() * 2);
+        const std::vector<uint16_t> xh = pack_heads_bf3(t[6], 4, t[10], 2, 128);
+        if (!rc) rc = upload(e, p.hdx, xh.data(), xh.size() * 2);
     }
     up(p.hd, pack_heads(t[6], 4, t[10], 2, 128));
     float hb[6] = {t[7][0], t[7][1], t[7][2], t[7][3], t[11][0], t[11][1]};
@@ -663,7 +686,7 @@ extern "C" int az_load_weights(az_engine *e, int slot, const float *const *t)
     p.w.hd = (const float *)p.hd.p; p.w.pf = (const float *)p.pf.p; p.w.vf = (const float *)p.vf.p;
     p.w.c1b = (const float *)p.c1b.p; p.w.c2b = (const float *)p.c2b.p; p.w.c3b = (const float *)p.c3b.p;
     p.w.hdb = (const float *)p.hdb.p; p.w.pfb = (const float *)p.pfb.p; p.w.vfb = (const float *)p.vfb.p;
-    p.w.c2x = p.c2x.p; p.w.c3x = p.c3x.p;
+    p.w.c2x = p.c2x.p; p.w.c3x = p.c3x.p; p.w.hdx = p.hdx.p;
     e->cache_gen++;           // evaluations cached under the previous weights never match again
     each_state(e, [&](DevState &d) { d.v2w[slot] = (const float *)p.v2w.p; d.v2b[slot] = (const float *)p.v2b.p; d.cache_gen = e->cache_gen; });
     p.loaded = true;

@@ -34,7 +34,7 @@ struct NetWeights {
     // MFMA-fragment packed (see pack_* in az_engine.hip): [ntile][kstep/4][lane][4]
     const float *c1, *c2, *c3, *hd, *pf, *vf;
     const float *c1b, *c2b, *c3b, *hdb, *pfb, *vfb;   // biases (hdb: 4 policy_conv + 2 value_conv)
-    const void *c2x, *c3x;                            // conv2 / conv3 split three ways into bf16 fragments (az_net_bf3.h), or null
+    const void *c2x, *c3x, *hdx;                      // conv2 / conv3 / head convs split three ways into bf16 fragments (az_net_bf3.h), or null
 };
 
 __host__ __device__ constexpr int up16(int x) { return x + ((16 - (x % 32) + 32) % 32); }   // smallest y >= x, y == 16 (mod 32)
@@ -133,34 +133,7 @@ __device__ __forceinline__ int pk_index(int ci, int pos)
 {
     return ((((ci >> 4) * 4 + (ci & 3)) * GEO::CS + pos) << 2) + ((ci >> 2) & 3);
 }
-enum { CONV_OUT_PACKED = 0, CONV_OUT3 = 1, CONV_OUT_RESIDUAL = 2,     // RESIDUAL: relu(acc + bias + out[same index]) in place
-       CONV_OUT_BF3 = 3 };                                             // relu(acc + bias) split into three bf16 images (az_net_bf3.h)
-
-// ---- three-way bfloat16 split of an activation (the fp32-emulating trunk, az_net_bf3.h) ----
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// two floats -> packed bf16 pair (round to nearest even; element 0 in the low half)
-__device__ __forceinline__ unsigned pk_bf16(float a, float b)
-{
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
-}
-__device__ __forceinline__ float bf_lo(unsigned p) { return __uint_as_float(p << 16); }
-__device__ __forceinline__ float bf_hi(unsigned p) { return __uint_as_float(p & 0xFFFF0000u); }
-// An image of C channels is 3 * C/8 planes of CS 16-byte slots: plane (split * C/8 + ci/8), slot = padded position, 8
-// consecutive channels per slot.  v[0..3] = channels co .. co+3 (co % 4 == 0) at position pos -> hi, mid, lo planes.
-template <class G, int C>
-__device__ __forceinline__ void store_bf3(uint2 *img, int co, int pos, const float (&v)[4])
-{
-    constexpr int NCG = C / 8;
-    const unsigned h0 = pk_bf16(v[0], v[1]), h1 = pk_bf16(v[2], v[3]);
-    const float r0 = v[0] - bf_lo(h0), r1 = v[1] - bf_hi(h0), r2 = v[2] - bf_lo(h1), r3 = v[3] - bf_hi(h1);     // exact
-    const unsigned m0 = pk_bf16(r0, r1), m1 = pk_bf16(r2, r3);
-    const unsigned l0 = pk_bf16(r0 - bf_lo(m0), r1 - bf_hi(m0)), l1 = pk_bf16(r2 - bf_lo(m1), r3 - bf_hi(m1));
-    uint2 *p = img + (((co >> 3) * G::CS + pos) << 1) + ((co >> 2) & 1);        // 8-byte units: slot * 2 + half
-    p[0] = uint2{h0, h1};
-    p[NCG * G::CS * 2] = uint2{m0, m1};
-    p[NCG * G::CS * 4] = uint2{l0, l1};
-}
+enum { CONV_OUT_PACKED = 0, CONV_OUT3 = 1, CONV_OUT_RESIDUAL = 2 };   // RESIDUAL: relu(acc + bias + out[same index]) in place
 
 // One conv layer on the workgroup's LDS image, computed as D[co][cell] = sum_k W[co][k] * X[k][cell]:
 // the weight fragment is the MFMA A operand (row = output channel), the activation fragment the B operand
@@ -297,17 +270,6 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
                 const int m = mt * 16 + r16;
                 const bool valid = cellof[m] != 0xFFFFu;
                 const int pos = wpos[m];
-                if constexpr (MODE == CONV_OUT_BF3) {
-                    if (valid) {
-                        float v4[4];
-#pragma unroll
-                        for (int rg = 0; rg < 4; rg++) {
-                            const float x = acc[t][i][rg] + bco[rg];
-                            v4[rg] = x > 0.0f ? x : 0.0f;
-                        }
-                        store_bf3<G, COUT>(reinterpret_cast<uint2 *>(out), nt * 16 + q * 4, pos, v4);
-                    }
-                } else {
 #pragma unroll
                 for (int rg = 0; rg < 4; rg++) {
                     const int co = nt * 16 + q * 4 + rg;      // = 16*cg + 4*e + q' with cg = nt, e = q, q' = rg
@@ -321,7 +283,6 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
                             out[oi] = r > 0.0f ? r : 0.0f;
                         }
                     } else if (valid) out[pk_index<G>(co, pos)] = v;
-                }
                 }
             }
         }

@@ -4,80 +4,194 @@
 // 16 x the K per cycle.  Here every conv operand x is split into three bfloat16 parts, x = hi + mid + lo (8 + 8 + 8
 // mantissa bits, each part the round-to-nearest bf16 of what the previous parts left over), and a product w * a is
 // accumulated in float32 from the six largest of the nine cross products:
-//     w_lo a_hi + w_hi a_lo + w_mid a_mid + w_mid a_hi + w_hi a_mid + w_hi a_hi        (dropped: <= 2^-24 relative)
+//     w_lo a_hi + w_mid a_hi + w_hi a_hi + w_mid a_mid + w_hi a_mid + w_hi a_lo        (dropped: <= 2^-24 relative)
 // i.e. 6 bf16 MFMAs per 16x16 tile and 32 k instead of 8 f32 MFMAs: a 2.67 x ceiling over k_trunk at fp32-like accuracy.
 // NOT the canonical fp order: results agree with the oracle within a tolerance (tests/test_bf16x3_gpu.py: logits 2e-5,
 // P 1e-6, value 2e-6 -- the tolerances the build already grants against the Python reference's torch numbers), not bit for
-// bit, so the mode is never the default (az_set_trunk_mode).  conv1 (K = 36, 1 % of the work) and the 1x1 head convs stay
-// on the f32 MFMA; conv2 and conv3 (99 %) run here.
+// bit, so the mode is never the default (az_set_trunk_mode).  conv1 (K = 36, 1 % of the work) stays on the f32 MFMA; conv2,
+// conv3 and the 1x1 head convs run on the bf16 MFMA.
 //
-// LDS images: an activation image is a list of PLANES of CS 16-byte slots; plane (split * C/8 + ci/8), slot = position in
+// LDS images: an activation image is a list of PLANES of CS 16-byte slots; plane (3 * (ci/8) + split), slot = position in
 // the zero-padded board image, 8 consecutive channels per slot -- exactly the B fragment of one lane (k = 8 (lane >> 4) + j),
 // so one ds_read_b128 per split feeds an MFMA, and the 16 lanes of a fragment row read 16 consecutive slots (CS % 16 == 0:
 // conflict-free).  The 32-channel image (conv1 out) occupies planes 0..11 of the region the 64-channel image (conv2 out,
 // 24 planes) later overlays; the padding rings coincide, so they are zeroed once per board.  conv2 and conv3 keep their
 // outputs in accumulators until every wave has finished reading the inputs (one barrier), then write over them.
+//
+// A wave owns ONE 16-channel tile of a layer and its share of the 16-cell tiles (all of them in conv3).  Measured at n = 15
+// and rejected: two channel tiles per wave (halves the LDS reads, 6 % surplus cell tiles: 49.8 us per 256 boards against
+// 47.6), the MFMAs of two or three cell tiles interleaved (49.2 / 49.7 us).
 #pragma once
 #include "az_net.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#ifndef AZ_BF3_NTW
-#define AZ_BF3_NTW 1          // output-channel tiles per wave in conv3 (1: a wave owns one channel tile x all cell tiles)
-#endif
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ f32x4 mfma_bf(const uint4 &a, const uint4 &b, f32x4 c)
+__device__ __forceinline__ f32x4 mfma_bf(const uint4 &a, const uint4 &b, f32x4 c)         // k = 8 (lane >> 4) + j
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4 mfma_bf16k(const uint2 &a, const uint2 &b, f32x4 c)      // v_mfma_f32_16x16x16_bf16: k = 4 (lane >> 4) + j
+{
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
 
-enum { BF3_OUT_IMAGE = 0, BF3_OUT3 = 1 };
+// two floats -> packed bf16 pair (round to nearest even; element 0 in the low half)
+__device__ __forceinline__ unsigned pk_bf16(float a, float b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ float bf_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(unsigned p) { return __uint_as_float(p & 0xFFFF0000u); }
+
+// four floats -> their hi / mid / lo bf16 parts, four packed values (8 bytes) per part
+__device__ __forceinline__ void split_bf3(const float (&v)[4], uint2 (&s)[3])
+{
+    const unsigned h0 = pk_bf16(v[0], v[1]), h1 = pk_bf16(v[2], v[3]);
+    const float r0 = v[0] - bf_lo(h0), r1 = v[1] - bf_hi(h0), r2 = v[2] - bf_lo(h1), r3 = v[3] - bf_hi(h1);     // exact
+    const unsigned m0 = pk_bf16(r0, r1), m1 = pk_bf16(r2, r3);
+    const unsigned l0 = pk_bf16(r0 - bf_lo(m0), r1 - bf_hi(m0)), l1 = pk_bf16(r2 - bf_lo(m1), r3 - bf_hi(m1));
+    s[0] = uint2{h0, h1};
+    s[1] = uint2{m0, m1};
+    s[2] = uint2{l0, l1};
+}
+
+// v[0..3] = channels co .. co+3 (co % 4 == 0) at padded position pos -> the hi, mid, lo planes of channel group co / 8
+template <class G>
+__device__ __forceinline__ void store_bf3(uint2 *img, int co, int pos, const float (&v)[4])
+{
+    uint2 s[3];
+    split_bf3(v, s);
+    uint2 *p = img + (((co >> 3) * 3 * G::CS + pos) << 1) + ((co >> 2) & 1);    // 8-byte units: slot * 2 + half
+    p[0] = s[0];
+    p[G::CS * 2] = s[1];
+    p[G::CS * 4] = s[2];
+}
+
+// the six products, operand order (weight split, activation split): the activation's hi part -- the fragment read first --
+// is used first, its lo part last
+__device__ constexpr int BF3_WS[6] = {2, 1, 0, 1, 0, 0}, BF3_AS[6] = {0, 0, 0, 1, 1, 2};
+
+// What a wave needs from global memory before its first MFMA of a layer, requested long before (at the top of the kernel
+// or a layer ahead) so that no L2 round trip sits on the critical path between the layers.
+struct Bf3Pre {
+    float4 c1w[3];          // conv1: the 9 k-steps of the wave's channel tile (f32 MFMA fragments)
+    float b1[4], b2[4], b3[4];   // biases of the wave's channel tile in conv1 / conv2 / conv3, rows 4 (lane >> 4) .. + 3
+    uint2 hw[3];            // head-conv fragments of the wave's conv3 tile (hi, mid, lo)
+};
+
+// conv1 (4 -> 32, K = 36) on the f32 MFMA like az_net.h's conv_layer<.., 4, 32, ..>, output split into the 32-channel image
+template <class G>
+__device__ __forceinline__ void conv1_bf3(const float *in, uint2 *out, const Bf3Pre &pre, const unsigned short *wpos,
+                                          const unsigned short *cellof, int wave, int lane)
+{
+    constexpr int NG = 2, MG = G::NW / NG, MTW = (G::MT + MG - 1) / MG;
+    const int ng = wave % NG, mg = wave / NG;
+    const int q = lane >> 4, r16 = lane & 15;
+    f32x4 acc[MTW];
+    int rb[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; i++) {
+        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int mt = mg + i * MG;
+        const int m = (mt < G::MT ? mt : 0) * 16 + r16;        // a surplus tile aliases tile 0 (computed, never written back)
+        rb[i] = (int)wpos[m] - (G::PW + 1) + q * G::CS;
+    }
+    const float bk[12] = {pre.c1w[0].x, pre.c1w[0].y, pre.c1w[0].z, pre.c1w[0].w, pre.c1w[1].x, pre.c1w[1].y, pre.c1w[1].z, pre.c1w[1].w,
+                          pre.c1w[2].x, pre.c1w[2].y, pre.c1w[2].z, pre.c1w[2].w};
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+        const int toff = (tap / 3) * G::PW + (tap % 3);
+#pragma unroll
+        for (int i = 0; i < MTW; i++) acc[i] = mfma4(bk[tap], in[rb[i] + toff], acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < MTW; i++) {
+        const int mt = mg + i * MG;
+        if (mt < G::MT) {
+            const int m = mt * 16 + r16;
+            if (cellof[m] != 0xFFFFu) {
+                float v[4];
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) {
+                    const float x = acc[i][rg] + pre.b1[rg];
+                    v[rg] = x > 0.0f ? x : 0.0f;
+                }
+                store_bf3<G>(out, ng * 16 + q * 4, wpos[m], v);
+            }
+        }
+    }
+}
+
+// the weight fragments of K-block kb of the wave's channel tile: packed [tile][K-block][split][lane][8 bf16]
+template <int KB>
+__device__ __forceinline__ void bf3_weights(const uint4 *__restrict__ wp, int tile, int kb, int lane, uint4 (&w)[3])
+{
+    const uint4 *p = wp + ((size_t)(tile * KB + kb) * 3) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < 3; s++) w[s] = p[s * 64];
+}
+
+// Issue order of one K-block, pinned with sched_group_barrier: per cell tile one LDS read (a fragment of the NEXT tile)
+// behind each of the first three MFMAs, then the other three MFMAs.
+template <int TILES>
+__device__ __forceinline__ void bf3_sched_tiles()
+{
+    if constexpr (TILES > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 LDS read (b128)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        bf3_sched_tiles<TILES - 1>();
+    }
+}
+
+enum { BF3_OUT_IMAGE = 0, BF3_OUT_HEADS = 1 };
 
 // One 3x3 conv layer, D[co][cell] = sum_k W[co][k] X[k][cell], k = tap * CIN + ci, on the bf16 MFMA with both operands
-// split three ways.  A wave owns NTW channel tiles x MTW cell tiles; per K-block of 32 (one tap, 32 channels) and cell
-// tile it reads three activation fragments from LDS (prefetched one tile ahead) and issues 6 * NTW MFMAs; the weight
-// fragments (packed [tile][K-block][split][lane][8] at az_load_weights) come from L2 one K-block ahead.
-// MODE BF3_OUT_IMAGE: barrier, relu(acc + bias) split into the C = COUT image at out;  BF3_OUT3: barrier, relu(acc + bias)
-// as float32 [co][cell] (stride CS3) for the head convs.
-template <class G, int CIN, int COUT, int MODE, int NTW_>
-__device__ __forceinline__ void conv_layer_bf3(const uint4 *in, void *out, const uint4 *__restrict__ wp,
-                                               const float *__restrict__ bias, const unsigned short *wpos,
+// split three ways.  A wave owns one channel tile x MTW cell tiles; per K-block of 32 (one tap, 32 channels) and cell tile
+// it reads three activation fragments from LDS (a tile ahead) and issues 6 MFMAs; the weight fragments of the next K-block
+// are requested from L2 before the block's MFMAs (w0 = the first block's, requested by the caller a layer ahead).
+// MODE BF3_OUT_IMAGE: barrier, relu(acc + bias) split into the COUT-channel image at out.
+// MODE BF3_OUT_HEADS (conv3, every wave owns all cell tiles): the 1x1 head convs (net.py:64,69) straight from the
+// accumulators -- a 16-channel x 16-cell result tile is, lane for lane, the B operand of v_mfma_f32_16x16x16_bf16
+// (k = 4 (lane >> 4) + register), so each wave multiplies its channel tile with its 16 columns of the head weights
+// (hw: [tile][split][lane][4] bf16, rows = head channels) and leaves partial sums [wave][head][cell] at out after the
+// barrier; the caller adds the waves up.
+template <class G, int CIN, int COUT, int MODE>
+__device__ __forceinline__ void conv_layer_bf3(const uint4 *in, void *out, const uint4 *__restrict__ wp, const uint4 (&w0)[3],
+                                               const float (&bco)[4], const uint2 (&hw)[3], const unsigned short *wpos,
                                                const unsigned short *cellof, int wave, int lane)
 {
-    constexpr int NT = COUT / 16;
-    constexpr int NTW = NTW_ <= NT ? NTW_ : NT;
-    constexpr int NG = NT / NTW;
+    constexpr int NG = COUT / 16;              // channel tiles = wave columns
     constexpr int MG = (G::NW / NG) > 0 ? (G::NW / NG) : 1;
     constexpr int MTW = (G::MT + MG - 1) / MG;
-    constexpr int NCG = CIN / 8;               // 8-channel planes per split
     constexpr int KBT = CIN / 32;              // K-blocks per tap
     constexpr int KB = 9 * KBT;
     static_assert(NG * MG == G::NW, "wave grid does not cover the workgroup");
     const int ng = wave % NG, mg = wave / NG;
     const int q = lane >> 4, r16 = lane & 15;
 
-    f32x4 acc[NTW][MTW];
-#pragma unroll
-    for (int t = 0; t < NTW; t++)
-#pragma unroll
-        for (int i = 0; i < MTW; i++) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int ra[MTW];                               // slot of the window's top-left corner in plane q
+    f32x4 acc[MTW];
+    int ra[MTW];                               // slot of the window's top-left corner in the lane's channel group (hi plane)
 #pragma unroll
     for (int i = 0; i < MTW; i++) {
+        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int mt = mg + i * MG;
         const int m = (mt < G::MT ? mt : 0) * 16 + r16;        // a surplus tile aliases tile 0 (computed, never written back)
-        ra[i] = (int)wpos[m] - (G::PW + 1) + q * G::CS;
+        ra[i] = (int)wpos[m] - (G::PW + 1) + q * 3 * G::CS;
     }
-    const uint4 *wl[NTW];
+    uint4 wc[3], wn[3];
 #pragma unroll
-    for (int t = 0; t < NTW; t++) wl[t] = wp + (size_t)(ng * NTW + t) * KB * 3 * 64 + lane;
-    uint4 wc[NTW][3], wn[NTW][3];
+    for (int s = 0; s < 3; s++) wc[s] = w0[s];
+    uint4 fa[2][3];
 #pragma unroll
-    for (int t = 0; t < NTW; t++)
-#pragma unroll
-        for (int s = 0; s < 3; s++) wc[t][s] = wl[t][s * 64];
-    uint4 a0[3], a1[3];
-#pragma unroll
-    for (int s = 0; s < 3; s++) a0[s] = in[ra[0] + s * NCG * G::CS];
+    for (int s = 0; s < 3; s++) fa[0][s] = in[ra[0] + s * G::CS];
     for (int tap = 0; tap < 9; tap++) {
         const int toff = (tap / 3) * G::PW + (tap % 3);
         const int tn = tap + 1 < 9 ? tap + 1 : tap;
@@ -85,71 +199,75 @@ __device__ __forceinline__ void conv_layer_bf3(const uint4 *in, void *out, const
 #pragma unroll
         for (int sq = 0; sq < KBT; sq++) {
             const int kb = tap * KBT + sq;
-            const int kn = kb + 1 < KB ? kb + 1 : kb;
-#pragma unroll
-            for (int t = 0; t < NTW; t++)
-#pragma unroll
-                for (int s = 0; s < 3; s++) wn[t][s] = wl[t][(size_t)(kn * 3 + s) * 64];
-            const int off = sq * 4 * G::CS + toff;
-            const int offn = sq + 1 < KBT ? (sq + 1) * 4 * G::CS + toff : toffn;      // first tile of the next K-block
+            bf3_weights<KB>(wp, ng, kb + 1 < KB ? kb + 1 : kb, lane, wn);
+            __builtin_amdgcn_sched_barrier(0);         // the next K-block's weights are requested before this block's MFMAs, not after
+            const int off = sq * 12 * G::CS + toff;    // a K-block = 4 channel groups x 3 split planes
+            const int offn = sq + 1 < KBT ? (sq + 1) * 12 * G::CS + toff : toffn;      // the next K-block
 #pragma unroll
             for (int i = 0; i < MTW; i++) {
-                uint4 *cur = (i & 1) ? a1 : a0;
-                uint4 *nxt = (i & 1) ? a0 : a1;
+                uint4 *cur = fa[i & 1], *nxt = fa[(i & 1) ^ 1];
                 const int an = i + 1 < MTW ? ra[i + 1] + off : ra[0] + offn;
 #pragma unroll
-                for (int s = 0; s < 3; s++) nxt[s] = in[an + s * NCG * G::CS];
+                for (int s = 0; s < 3; s++) nxt[s] = in[an + s * G::CS];
 #pragma unroll
-                for (int t = 0; t < NTW; t++) {
-                    acc[t][i] = mfma_bf(wc[t][2], cur[0], acc[t][i]);       // small terms first
-                    acc[t][i] = mfma_bf(wc[t][0], cur[2], acc[t][i]);
-                    acc[t][i] = mfma_bf(wc[t][1], cur[1], acc[t][i]);
-                    acc[t][i] = mfma_bf(wc[t][1], cur[0], acc[t][i]);
-                    acc[t][i] = mfma_bf(wc[t][0], cur[1], acc[t][i]);
-                    acc[t][i] = mfma_bf(wc[t][0], cur[0], acc[t][i]);
-                }
+                for (int p = 0; p < 6; p++) acc[i] = mfma_bf(wc[BF3_WS[p]], cur[BF3_AS[p]], acc[i]);
             }
-            if constexpr ((MTW & 1) != 0) {        // an odd number of tiles leaves the prefetched fragments in a1
+            if constexpr ((MTW & 1) != 0) {            // an odd number of tiles leaves the prefetched fragments in fa[1]
 #pragma unroll
-                for (int s = 0; s < 3; s++) a0[s] = a1[s];
+                for (int s = 0; s < 3; s++) fa[0][s] = fa[1][s];
             }
+            bf3_sched_tiles<MTW>();
 #pragma unroll
-            for (int i = 0; i < MTW; i++)
-#pragma unroll
-                for (int s = 0; s < 3; s++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NTW, 0);   // 2*NTW MFMAs
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // 1 LDS read (b128)
-                }
-#pragma unroll
-            for (int t = 0; t < NTW; t++)
-#pragma unroll
-                for (int s = 0; s < 3; s++) wc[t][s] = wn[t][s];
+            for (int s = 0; s < 3; s++) wc[s] = wn[s];
         }
     }
-    __syncthreads();                           // every wave has finished reading the input image: the output overlays it
+    if constexpr (MODE == BF3_OUT_HEADS) {
+        static_assert(MG == 1, "the fused head convs need all cell tiles of a channel tile in one wave");
+        f32x4 hacc[MTW];
 #pragma unroll
-    for (int t = 0; t < NTW; t++) {
-        const int nt = ng * NTW + t;
-        float bco[4];
+        for (int i = 0; i < MTW; i++) {
+            float v[4];
 #pragma unroll
-        for (int rg = 0; rg < 4; rg++) bco[rg] = bias[nt * 16 + q * 4 + rg];
+            for (int rg = 0; rg < 4; rg++) {
+                const float x = acc[i][rg] + bco[rg];
+                v[rg] = x > 0.0f ? x : 0.0f;
+            }
+            uint2 xs[3];
+            split_bf3(v, xs);
+            f32x4 h = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int p = 0; p < 6; p++) h = mfma_bf16k(hw[BF3_WS[p]], xs[BF3_AS[p]], h);
+            hacc[i] = h;
+        }
+        __syncthreads();                       // every wave has finished reading the conv3 input image: the partial sums overlay it
+        float *o = reinterpret_cast<float *>(out) + wave * 6 * G::MR;
+        // result rows = head channels: lanes q = 0 hold channels 0..3, q = 1 channels 4..5 (rows 6..15 are padding)
+#pragma unroll
+        for (int i = 0; i < MTW; i++) {
+            const int m = i * 16 + r16;
+            if (q == 0) {
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) o[rg * G::MR + m] = hacc[i][rg];
+            } else if (q == 1) {
+                o[4 * G::MR + m] = hacc[i][0];
+                o[5 * G::MR + m] = hacc[i][1];
+            }
+        }
+    } else {
+        __syncthreads();                       // every wave has finished reading the input image: the output overlays it
 #pragma unroll
         for (int i = 0; i < MTW; i++) {
             const int mt = mg + i * MG;
             if (mt < G::MT) {
                 const int m = mt * 16 + r16;
-                float v[4];
+                if (cellof[m] != 0xFFFFu) {
+                    float v[4];
 #pragma unroll
-                for (int rg = 0; rg < 4; rg++) {
-                    const float x = acc[t][i][rg] + bco[rg];
-                    v[rg] = x > 0.0f ? x : 0.0f;
-                }
-                if constexpr (MODE == BF3_OUT3) {
-                    float *o = reinterpret_cast<float *>(out);
-#pragma unroll
-                    for (int rg = 0; rg < 4; rg++) o[(nt * 16 + q * 4 + rg) * G::CS3 + m] = v[rg];
-                } else {
-                    if (cellof[m] != 0xFFFFu) store_bf3<G, COUT>(reinterpret_cast<uint2 *>(out), nt * 16 + q * 4, wpos[m], v);
+                    for (int rg = 0; rg < 4; rg++) {
+                        const float x = acc[i][rg] + bco[rg];
+                        v[rg] = x > 0.0f ? x : 0.0f;
+                    }
+                    store_bf3<G>(reinterpret_cast<uint2 *>(out), ng * 16 + q * 4, wpos[m], v);
                 }
             }
         }
@@ -162,6 +280,8 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk_bf3(DevState d, NetWeights
 {
     typedef NetGeo<N> G;
     constexpr int NTH = AZ_NW * 64;
+    static_assert(AZ_NW == 8, "the emulated trunk is laid out for 8 waves: 2 / 4 / 8 channel tiles in conv1 / conv2 / conv3");
+    static_assert(AZ_NW * 6 * G::MR <= G::LDSF, "head-conv partial sums do not fit the image region");
     __shared__ __attribute__((aligned(16))) float lds[G::LDSF];
     __shared__ unsigned short wpos[G::MR];
     __shared__ unsigned short cellof[G::MR];
@@ -179,58 +299,105 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk_bf3(DevState d, NetWeights
             if (leaf_needs_net(kind) && d.s_status[b] == SLOT_ACTIVE && d.s_net[b] == net_id) atomicOr(&any_active, 1);
         }
     }
-    __syncthreads();
-    if (!any_active) return;
+    // ---- requests that do not depend on anything: the wave's conv1 fragments, biases, head fragments, conv2's first K-block
+    Bf3Pre pre;
+    uint4 w2[3], w3[3];
+    {
+        const int q = lane >> 4;
+        const float4 *c1 = reinterpret_cast<const float4 *>(w.c1) + (size_t)(wave % 2) * 3 * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < 3; j++) pre.c1w[j] = c1[j * 64];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            pre.b1[rg] = w.c1b[(wave % 2) * 16 + q * 4 + rg];
+            pre.b2[rg] = w.c2b[(wave % 4) * 16 + q * 4 + rg];
+            pre.b3[rg] = w.c3b[wave * 16 + q * 4 + rg];
+        }
+        const uint2 *hx = reinterpret_cast<const uint2 *>(w.hdx) + (size_t)wave * 3 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < 3; s++) pre.hw[s] = hx[s * 64];
+        bf3_weights<9>(reinterpret_cast<const uint4 *>(w.c2x), wave % 4, 0, lane, w2);
+    }
     // region X = 24 planes of CS slots (96 * CS floats): conv1 out in planes 0..11, conv2 out in planes 0..23; the float32
     // input planes of conv1 are the bytes of plane 12
     float *inP = lds + 48 * G::CS;
-    {
-        float4 *z = reinterpret_cast<float4 *>(lds);
-        for (int i = tid; i < (96 * G::CS) / 4; i += NTH) z[i] = float4{0.f, 0.f, 0.f, 0.f};
-    }
-    for (int m = tid; m < G::MR; m += NTH) {
-        int pos, cell;
-        if constexpr (G::ROWT) {
-            const int t = m >> 4, c = m & 15, g = t / N, r = t - g * N;
-            pos = g * G::PP + (r + 1) * G::PW + (c + 1);
-            cell = c < N ? g * G::nn + r * N + c : 0xFFFF;
-        } else {
-            const int g = m / G::nn, p = m - g * G::nn, r = p / N, c = p - r * N;
-            pos = m < G::M ? g * G::PP + (r + 1) * G::PW + (c + 1) : G::PW + 1;
-            cell = m < G::M ? m : 0xFFFF;
+    // Every thread requests the leaf words of its cells (games.py:86-129 encode) before it is known whether the group has
+    // anything to evaluate: the loads are in flight while the image is zeroed.
+    constexpr int EPT = (G::MR + NTH - 1) / NTH;
+    int e_pos[EPT];
+    bool e_me[EPT], e_op[EPT], e_last[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        const int m = tid + e * NTH;
+        int pos = G::PW + 1, cell = 0xFFFF;
+        if (m < G::MR) {
+            if constexpr (G::ROWT) {
+                const int t = m >> 4, c = m & 15, g = t / N, r = t - g * N;
+                pos = g * G::PP + (r + 1) * G::PW + (c + 1);             // c == N is the right padding cell of the row
+                cell = c < N ? g * G::nn + r * N + c : 0xFFFF;
+            } else {
+                const int g = m / G::nn, p = m - g * G::nn, r = p / N, c = p - r * N;
+                pos = m < G::M ? g * G::PP + (r + 1) * G::PW + (c + 1) : G::PW + 1;
+                cell = m < G::M ? m : 0xFFFF;
+            }
+            wpos[m] = (unsigned short)pos;
+            cellof[m] = (unsigned short)cell;
         }
-        wpos[m] = (unsigned short)pos;
-        cellof[m] = (unsigned short)cell;
-    }
-    __syncthreads();
-    for (int m = tid; m < G::MR; m += NTH) {          // games.py:86-129 encode
-        const int cell = cellof[m];
+        e_pos[e] = pos;
+        e_me[e] = e_op[e] = e_last[e] = false;
         if (cell != 0xFFFF) {
             const int g = cell / G::nn, p = cell - g * G::nn;
             const int b = b0 + g;
             if (b < d.B) {
                 const u64 *lf = d.leaf + (size_t)b * 8;
-                const int pos = wpos[m];
-                if ((lf[p >> 6] >> (p & 63)) & 1ull) inP[pos] = 1.0f;
-                if ((lf[4 + (p >> 6)] >> (p & 63)) & 1ull) inP[G::CS + pos] = 1.0f;
-                if (d.leaf_last[b] == p) inP[2 * G::CS + pos] = 1.0f;
+                e_me[e] = (lf[p >> 6] >> (p & 63)) & 1ull;
+                e_op[e] = (lf[4 + (p >> 6)] >> (p & 63)) & 1ull;
+                e_last[e] = d.leaf_last[b] == p;
             }
         }
     }
+    {
+        float4 *z = reinterpret_cast<float4 *>(lds);
+        for (int i = tid; i < (96 * G::CS) / 4; i += NTH) z[i] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    if (!any_active) return;
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        if (e_me[e]) inP[e_pos[e]] = 1.0f;
+        if (e_op[e]) inP[G::CS + e_pos[e]] = 1.0f;
+        if (e_last[e]) inP[2 * G::CS + e_pos[e]] = 1.0f;
+    }
     __syncthreads();
     AZ_STAMP(1);
-    conv_layer<G, 4, 32, CONV_OUT_BF3>(inP, lds, w.c1, w.c1b, wpos, cellof, wave, lane);
+    conv1_bf3<G>(inP, reinterpret_cast<uint2 *>(lds), pre, wpos, cellof, wave, lane);
+    bf3_weights<18>(reinterpret_cast<const uint4 *>(w.c3x), wave, 0, lane, w3);       // conv3's first K-block, a layer ahead
     __syncthreads();
     for (int i = tid; i < 3 * G::CS; i += NTH) inP[i] = 0.0f;      // plane 12 is part of conv2's output image
     AZ_STAMP(2);
-    conv_layer_bf3<G, 32, 64, BF3_OUT_IMAGE, 1>(reinterpret_cast<const uint4 *>(lds), lds, reinterpret_cast<const uint4 *>(w.c2x),
-                                                w.c2b, wpos, cellof, wave, lane);
+    conv_layer_bf3<G, 32, 64, BF3_OUT_IMAGE>(reinterpret_cast<const uint4 *>(lds), lds, reinterpret_cast<const uint4 *>(w.c2x), w2, pre.b2,
+                                             pre.hw, wpos, cellof, wave, lane);
     __syncthreads();
     AZ_STAMP(3);
-    conv_layer_bf3<G, 64, 128, BF3_OUT3, AZ_BF3_NTW>(reinterpret_cast<const uint4 *>(lds), lds, reinterpret_cast<const uint4 *>(w.c3x),
-                                                     w.c3b, wpos, cellof, wave, lane);
+    // conv3 with the 1x1 head convs fused into its epilogue: partial sums [wave][head channel][cell] in LDS, added up here
+    conv_layer_bf3<G, 64, 128, BF3_OUT_HEADS>(reinterpret_cast<const uint4 *>(lds), lds, reinterpret_cast<const uint4 *>(w.c3x), w3, pre.b3,
+                                              pre.hw, wpos, cellof, wave, lane);
     __syncthreads();
     AZ_STAMP(4);
-    trunk_heads<G>(d, w, net_id, feat, lds, cellof, b0, wave, lane);
+    for (int o = tid; o < 6 * G::MR; o += NTH) {
+        const int j = o / G::MR, m = o - j * G::MR;
+        const int cell = cellof[m];
+        if (cell != 0xFFFF) {
+            const int g = cell / G::nn, p = cell - g * G::nn;
+            const int b = b0 + g;
+            if (b < d.B && d.s_net[b] == net_id) {
+                float v = lds[o];
+#pragma unroll
+                for (int wv = 1; wv < AZ_NW; wv++) v = v + lds[wv * 6 * G::MR + o];
+                v = v + w.hdb[j];
+                feat[(size_t)b * G::FROW + j * G::nn + p] = v > 0.0f ? v : 0.0f;      // net.py:64,69 flatten order
+            }
+        }
+    }
     AZ_STAMP(5);
 }

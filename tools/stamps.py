@@ -7,8 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import alphazero_piskvorky_amd as az
 from alphazero_piskvorky_amd import _capi
 from alphazero_piskvorky_amd.weights import synthetic_state_dict
-n, B = int(sys.argv[1]) if len(sys.argv) > 1 else 15, 1024
-e = az.Engine(n, 5 if n > 5 else 4, 8, B)
+n, B = int(sys.argv[1]) if len(sys.argv) > 1 else 15, 256      # one lane, one round of workgroups at n = 15
+e = az.Engine(n, 5 if n > 5 else 4, 8, B, engines=1)
 e.load_weights(synthetic_state_dict(n), 0)
 if len(sys.argv) > 2:
     e.set_trunk_mode(sys.argv[2])
