@@ -184,8 +184,9 @@ def test_real_net_search_bit_exact_vs_oracle(fixture, split):
                 assert r["action"] == int(z["action"][idx])
             else:
                 assert np.abs(r["N"] - z["N"][idx]).sum() <= max(4, S // 10)
-    # torch's priors differ from the canonical-order ones in the last bits, which can flip a near-tie in PUCT
-    assert exact >= 0.8 * total, f"only {exact}/{total} plies had the reference's visit counts"
+    # torch's priors differ from the canonical-order ones in the last bits, which could flip a near-tie in PUCT; on the frozen
+    # fixtures it flips none (the search is deterministic), and a regression of a single ply must not hide behind a budget
+    assert exact == total, f"only {exact}/{total} plies had the reference's visit counts"
     e.close()
 
 
@@ -261,7 +262,7 @@ def test_arena_vs_oracle_and_reference(split):
         w += ro["result"] == 1; l += ro["result"] == 2; d += ro["result"] == 3
     assert (r["wins"], r["losses"], r["draws"]) == (w, l, d)
     same = sum(np.array_equal(r["actions"][g][:int(r["nply"][g])], z["actions"][g][z["actions"][g] >= 0]) for g in range(G))
-    assert same >= G - 1
+    assert same == G        # frozen fixture, deterministic search: every game, not all but one
     if same == G:
         assert (r["wins"], r["losses"], r["draws"]) == (int(z["wins"]), int(z["losses"]), int(z["draws"]))
         assert abs(r["win_rate"] - float(z["win_rate"])) < 1e-12

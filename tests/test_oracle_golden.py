@@ -151,7 +151,9 @@ def test_real_net_games_teacher_forced(fixture):
                 assert r["action"] == int(z["action"][idx])
             else:
                 assert np.abs(r["N"] - z["N"][idx]).sum() <= max(4, S // 10)
-    assert exact >= 0.8 * total, f"only {exact}/{total} plies had identical visit counts"
+    # the fixtures are frozen and the search is deterministic: today every recorded ply reproduces the reference's visit counts,
+    # and a regression of a single ply must not hide behind a budget
+    assert exact == total, f"only {exact}/{total} plies had identical visit counts"
 
 
 def test_real_net_full_game_free_running():
@@ -169,7 +171,7 @@ def test_real_net_full_game_free_running():
             same += 1
             assert np.array_equal(r["z"], z["z"][sel])
             assert r["result"] == int(z["final"][sel[-1]])
-    assert same >= len(games) - 1
+    assert same == len(games)       # frozen fixture, deterministic search: every game, not all but one
 
 
 def test_augmentation_bug_compatible():
@@ -198,7 +200,7 @@ def test_arena_games_vs_reference():
         if r["nply"] == len(ref) and np.array_equal(r["actions"], ref):
             same += 1
         wins += r["result"] == 1; losses += r["result"] == 2; draws += r["result"] == 3
-    assert same >= z["actions"].shape[0] - 1
+    assert same == z["actions"].shape[0]      # frozen fixture, deterministic search: every game, not all but one
     if same == z["actions"].shape[0]:
         assert (wins, losses, draws) == (int(z["wins"]), int(z["losses"]), int(z["draws"]))
         assert abs((wins + 0.5 * draws) / (wins + losses + draws) - float(z["win_rate"])) < 1e-12
