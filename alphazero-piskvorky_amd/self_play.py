@@ -22,7 +22,7 @@ class SelfPlayManager:
                  temperature_schedule: Callable[[int], float] = default_temperature_schedule,
                  concurrent_games: int = None, augmentation: int = AZ_AUG_REFERENCE4, seed: int = None,
                  engines_per_gpu: int = None, subtree_reuse: bool = False, gather_to: int = None,
-                 eval_cache: int = 0, virtual_loss: int = 1):
+                 eval_cache: int = 0, virtual_loss: int = 1, trunk: str = "f32"):
         self.controller = controller
         self.device = device
         self.mcts_params = mcts_params or {"num_simulations": 100}
@@ -34,6 +34,7 @@ class SelfPlayManager:
         self.subtree_reuse = subtree_reuse    # opt-in search upgrade (mcts.py:17-22 TODO); off = the reference's fresh root every move
         self.eval_cache = eval_cache          # opt-in: positions kept in the device evaluation cache (mcts.py:17,22 TODO); results unchanged
         self.virtual_loss = virtual_loss      # opt-in: leaves per search and evaluation batch (mcts.py:17-22 TODO); 1 = sequential like the reference
+        self.trunk = trunk                    # opt-in: "bf16x3" = fp32-emulating conv trunk on the bf16 matrix cores (tolerance, not bit-exact)
         self.gather_to = gather_to            # multi-rank: None = every rank receives all records (all-gather); r = only rank r does
         self.last_counters = None
         self._engine = None
@@ -86,6 +87,8 @@ class SelfPlayManager:
         eng = self._eng(n, k, max(1, min(self.concurrent_games, max(mine, 1))))
         eng.load_weights(self.controller.net.state_dict(), 0)
         eng.set_subtree_reuse(self.subtree_reuse)
+        if eng.trunk_mode() != self.trunk:
+            eng.set_trunk_mode(self.trunk)
         T = np.array([float(self.temperature_schedule(m)) for m in range(n * n + 1)], dtype=np.float64)
         if mine > 0:
             self.last_counters = eng.selfplay(mine, seed0=seed0 + lo, temperature_table=T)

@@ -26,7 +26,7 @@ PROMOTION_THRESHOLD = 0.55          # promoter.py:19, strict ">" with draws coun
 
 
 def run(episodes, games, sims, eval_games, device="cuda:0", seed=0, model_dir=None, log=print, device_replay=False,
-        subtree_reuse=False):
+        subtree_reuse=False, trunk="f32"):
     """device_replay=True keeps the examples on the GPU from the episode-end gather to the optimizer step (packed records
     in a device ring, batches unpacked + augmented by az_examples_gather) instead of materialising Python tuples."""
     torch.manual_seed(seed)
@@ -38,7 +38,7 @@ def run(episodes, games, sims, eval_games, device="cuda:0", seed=0, model_dir=No
     # multi-rank: every rank plays its shard of the games; the records go to rank 0 only (the reference has one trainer,
     # train.py:95-104), rank 0 takes the optimizer steps and its weights are broadcast; only rank 0 writes model_dir
     manager = SelfPlayManager(candidate, device, mcts_params={"num_simulations": sims, "c_puct": C.SELF_PLAY_EXPLORATION_CONSTANT},
-                              seed=seed, subtree_reuse=subtree_reuse, gather_to=0 if world > 1 else None)
+                              seed=seed, subtree_reuse=subtree_reuse, gather_to=0 if world > 1 else None, trunk=trunk)
     evaluator = ModelEvaluator(game_class=Gomoku, print_games=False, device=device, seed=seed)
     promoter = ModelPromoter(model_dir, evaluator, lambda: GomokuNet(board_size=n), device, threshold=PROMOTION_THRESHOLD)
     buffer = ReplayBuffer(capacity=C.BUFFER_CAPACITY)
@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--eval-games", type=int, default=C.EVALUATION_GAMES)
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--model-dir", default=None)
+    ap.add_argument("--trunk", default="f32", choices=["f32", "bf16x3"], help="self-play conv trunk: f32 (bit-exact default) or the fp32-emulating bf16 trunk (opt-in)")
     ap.add_argument("--subtree-reuse", action="store_true", help="self-play keeps the chosen child's subtree between plies (opt-in search upgrade)")
     ap.add_argument("--device-replay", action="store_true", help="keep examples on the GPU (packed ring + on-device batch unpacking)")
     a = ap.parse_args()
@@ -105,7 +106,7 @@ def main():
         td.init_process_group("nccl", device_id=torch.device("cuda", local))
         a.device = f"cuda:{local}"
     run(a.episodes, a.games, a.sims, a.eval_games, a.device, model_dir=a.model_dir, device_replay=a.device_replay,
-        subtree_reuse=a.subtree_reuse)
+        subtree_reuse=a.subtree_reuse, trunk=a.trunk)
     if world > 1:
         td.barrier()
         td.destroy_process_group()

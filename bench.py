@@ -230,11 +230,18 @@ def main():
         # HBM bytes per launch from the committed PMC passes (FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as is)
         traffic, traffic_src = None, None
         try:
-            if a.model != "plain" or a.trunk != "f32":
+            if a.model != "plain":
                 raise KeyError("no PMC pass for this kernel yet")
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))[f"k_trunk<{n}>"]
-            traffic = pm["hbm_bytes_per_board"] * boards / launches
-            traffic_src = "profiles/r01_pmc_summary.json (separate --pmc passes, per board x boards per launch)"
+            if a.trunk == "f32":
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))[f"k_trunk<{n}>"]
+                traffic = pm["hbm_bytes_per_board"] * boards / launches
+                traffic_src = "profiles/r01_pmc_summary.json (separate --pmc passes, per board x boards per launch)"
+            else:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bf16x3_summary.json")))[f"k_trunk_bf3<{n}>"]
+                # FETCH_SIZE / WRITE_SIZE in KiB per dispatch; FETCH_SIZE doubled per the gfx950 note (16-B-per-lane streams count half)
+                per_board = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0 / (pm["grid"] / pm["workgroup"])
+                traffic = per_board * boards / launches
+                traffic_src = "profiles/r02_pmc_bf16x3_summary.json (separate --pmc passes, per board x boards per launch)"
         except Exception:
             pass
         # the rest of the path, priced against HBM with SURVEY 8(d)'s algorithmic bytes (reference semantics, fp32 edges):
