@@ -34,6 +34,7 @@ struct PackedNet {
     DevBuf c1, c2, c3, hd, pf, vf, c1b, c2b, c3b, hdb, pfb, vfb, v2w, v2b;
     DevBuf rblk[6], rblkb[6];          // ResidualBlock variant: the six 64->64 convs (c1/c1b hold the stem)
     DevBuf c2x, c3x, hdx;              // conv2 / conv3 / head convs split three ways into bf16 MFMA fragments (az_net_bf3.h)
+    DevBuf rblkx[6];                   // ... and the six 64 -> 64 convs of the ResidualBlock variant
     NetWeights w{};
     ResWeights rw{};
 };
@@ -646,7 +647,7 @@ extern "C" void az_destroy(az_engine *e)
         PackedNet &p = e->net[s];
         DevBuf *nb[] = {&p.c1, &p.c2, &p.c3, &p.hd, &p.pf, &p.vf, &p.c1b, &p.c2b, &p.c3b, &p.hdb, &p.pfb, &p.vfb, &p.v2w, &p.v2b, &p.c2x, &p.c3x, &p.hdx};
         for (DevBuf *b : nb) dev_free(*b);
-        for (int i = 0; i < 6; i++) { dev_free(p.rblk[i]); dev_free(p.rblkb[i]); }
+        for (int i = 0; i < 6; i++) { dev_free(p.rblk[i]); dev_free(p.rblkb[i]); dev_free(p.rblkx[i]); }
     }
     for (Lane &L : e->lanes)
         if (L.stream) g_streams.release(e->cfg.device, true, L.stream);
@@ -707,6 +708,14 @@ extern "C" int az_load_weights_resnet(az_engine *e, int slot, const float *const
     auto upraw = [&](DevBuf &b, const float *v, size_t cnt) { if (!rc) rc = upload(e, b, v, cnt * sizeof(float)); };
     up(p.c1, pack_conv(t[0], 64, 4)); upraw(p.c1b, t[1], 64);
     for (int i = 0; i < 6; i++) { up(p.rblk[i], pack_conv(t[2 + 2 * i], 64, 64)); upraw(p.rblkb[i], t[3 + 2 * i], 64); }
+    for (int i = 0; i < 6; i++) {
+        const std::vector<uint16_t> x = pack_conv_bf3(t[2 + 2 * i], 64, 64);
+        if (!rc) rc = upload(e, p.rblkx[i], x.data(), x.size() * 2);
+    }
+    {
+        const std::vector<uint16_t> xh = pack_heads_bf3(t[14], 2, t[16], 1, 64);
+        if (!rc) rc = upload(e, p.hdx, xh.data(), xh.size() * 2);
+    }
     up(p.hd, pack_heads(t[14], 2, t[16], 1, 64));
     float hb[3] = {t[15][0], t[15][1], t[17][0]};
     upraw(p.hdb, hb, 3);
@@ -717,6 +726,8 @@ extern "C" int az_load_weights_resnet(az_engine *e, int slot, const float *const
     p.rw.stem = (const float *)p.c1.p; p.rw.stemb = (const float *)p.c1b.p;
     for (int i = 0; i < 6; i++) { p.rw.blk[i] = (const float *)p.rblk[i].p; p.rw.blkb[i] = (const float *)p.rblkb[i].p; }
     p.rw.hd = (const float *)p.hd.p; p.rw.hdb = (const float *)p.hdb.p;
+    for (int i = 0; i < 6; i++) p.rw.blkx[i] = p.rblkx[i].p;
+    p.rw.hdx = p.hdx.p;
     p.w = NetWeights{};
     p.w.pf = (const float *)p.pf.p; p.w.vf = (const float *)p.vf.p;
     p.w.pfb = (const float *)p.pfb.p; p.w.vfb = (const float *)p.vfb.p;
@@ -1594,8 +1605,6 @@ extern "C" int az_set_trunk_mode(az_engine *e, int mode)
     if (!e) return AZ_ERR_INVALID;
     if (e->run.open) return fail(e, AZ_ERR_STATE, "az_set_trunk_mode: an episode is open");
     if (mode != AZ_TRUNK_F32 && mode != AZ_TRUNK_BF16X3) return fail(e, AZ_ERR_INVALID, "az_set_trunk_mode: unknown mode %d", mode);
-    if (mode == AZ_TRUNK_BF16X3 && e->cfg.model != AZ_MODEL_PLAIN)
-        return fail(e, AZ_ERR_INVALID, "az_set_trunk_mode: the fp32-emulating trunk exists for GomokuNet (AZ_MODEL_PLAIN) only");
     if (mode != e->trunk_mode) {
         e->trunk_mode = mode;
         e->cache_gen++;           // cached evaluations of the other arithmetic never match again

@@ -602,6 +602,7 @@ struct ResWeights {
     const float *stem, *stemb;
     const float *blk[6], *blkb[6];     // res1.conv1, res1.conv2, res2.conv1, ... (MFMA-fragment packed), folded biases
     const float *hd, *hdb;             // policy_conv (2) + value_conv (1) rows of one 16-row tile, folded biases [3]
+    const void *blkx[6], *hdx;         // the six 64 -> 64 convs and the head rows split three ways into bf16 fragments (az_net_bf3.h), or null
 };
 
 template <int N>

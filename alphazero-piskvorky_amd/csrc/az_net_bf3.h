@@ -82,12 +82,16 @@ struct Bf3Pre {
     uint2 hw[3];            // head-conv fragments of the wave's conv3 tile (hi, mid, lo)
 };
 
-// conv1 (4 -> 32, K = 36) on the f32 MFMA like az_net.h's conv_layer<.., 4, 32, ..>, output split into the 32-channel image
-template <class G>
-__device__ __forceinline__ void conv1_bf3(const float *in, uint2 *out, const Bf3Pre &pre, const unsigned short *wpos,
-                                          const unsigned short *cellof, int wave, int lane)
+// The first conv (4 -> COUT, K = 36: GomokuNet's conv1, the ResidualBlock net's stem) on the f32 MFMA like az_net.h's
+// conv_layer<.., 4, COUT, ..>, output split into the COUT-channel image; keep != nullptr also returns the wave's tiles as
+// float32 (the skip connection's operand of the first residual block).
+template <class G, int COUT>
+__device__ __forceinline__ void conv_first_bf3(const float *in, uint2 *out, const float4 (&c1w)[3], const float (&b1)[4],
+                                               const unsigned short *wpos, const unsigned short *cellof, int wave, int lane,
+                                               f32x4 *keep = nullptr)
 {
-    constexpr int NG = 2, MG = G::NW / NG, MTW = (G::MT + MG - 1) / MG;
+    constexpr int NG = COUT / 16, MG = G::NW / NG, MTW = (G::MT + MG - 1) / MG;
+    static_assert(NG * MG == G::NW, "wave grid does not cover the workgroup");
     const int ng = wave % NG, mg = wave / NG;
     const int q = lane >> 4, r16 = lane & 15;
     f32x4 acc[MTW];
@@ -99,8 +103,8 @@ __device__ __forceinline__ void conv1_bf3(const float *in, uint2 *out, const Bf3
         const int m = (mt < G::MT ? mt : 0) * 16 + r16;        // a surplus tile aliases tile 0 (computed, never written back)
         rb[i] = (int)wpos[m] - (G::PW + 1) + q * G::CS;
     }
-    const float bk[12] = {pre.c1w[0].x, pre.c1w[0].y, pre.c1w[0].z, pre.c1w[0].w, pre.c1w[1].x, pre.c1w[1].y, pre.c1w[1].z, pre.c1w[1].w,
-                          pre.c1w[2].x, pre.c1w[2].y, pre.c1w[2].z, pre.c1w[2].w};
+    const float bk[12] = {c1w[0].x, c1w[0].y, c1w[0].z, c1w[0].w, c1w[1].x, c1w[1].y, c1w[1].z, c1w[1].w,
+                          c1w[2].x, c1w[2].y, c1w[2].z, c1w[2].w};
 #pragma unroll
     for (int tap = 0; tap < 9; tap++) {
         const int toff = (tap / 3) * G::PW + (tap % 3);
@@ -110,17 +114,16 @@ __device__ __forceinline__ void conv1_bf3(const float *in, uint2 *out, const Bf3
 #pragma unroll
     for (int i = 0; i < MTW; i++) {
         const int mt = mg + i * MG;
+        float v[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const float x = acc[i][rg] + b1[rg];
+            v[rg] = x > 0.0f ? x : 0.0f;
+        }
+        if (keep) keep[i] = f32x4{v[0], v[1], v[2], v[3]};
         if (mt < G::MT) {
             const int m = mt * 16 + r16;
-            if (cellof[m] != 0xFFFFu) {
-                float v[4];
-#pragma unroll
-                for (int rg = 0; rg < 4; rg++) {
-                    const float x = acc[i][rg] + pre.b1[rg];
-                    v[rg] = x > 0.0f ? x : 0.0f;
-                }
-                store_bf3<G>(out, ng * 16 + q * 4, wpos[m], v);
-            }
+            if (cellof[m] != 0xFFFFu) store_bf3<G>(out, ng * 16 + q * 4, wpos[m], v);
         }
     }
 }
@@ -151,7 +154,9 @@ __device__ __forceinline__ void bf3_sched_tiles()
     }
 }
 
-enum { BF3_OUT_IMAGE = 0, BF3_OUT_HEADS = 1 };
+enum { BF3_OUT_IMAGE = 0, BF3_OUT_HEADS = 1,      // where the result goes
+       BF3_SKIP = 2,                                // relu(acc + bias + keep[tile]): the residual block's skip connection, from registers
+       BF3_KEEP = 4 };                              // keep[tile] = the layer's output (float32), the next block's skip operand
 
 // One 3x3 conv layer, D[co][cell] = sum_k W[co][k] X[k][cell], k = tap * CIN + ci, on the bf16 MFMA with both operands
 // split three ways.  A wave owns one channel tile x MTW cell tiles; per K-block of 32 (one tap, 32 channels) and cell tile
@@ -161,12 +166,12 @@ enum { BF3_OUT_IMAGE = 0, BF3_OUT_HEADS = 1 };
 // MODE BF3_OUT_HEADS (conv3, every wave owns all cell tiles): the 1x1 head convs (net.py:64,69) straight from the
 // accumulators -- a 16-channel x 16-cell result tile is, lane for lane, the B operand of v_mfma_f32_16x16x16_bf16
 // (k = 4 (lane >> 4) + register), so each wave multiplies its channel tile with its 16 columns of the head weights
-// (hw: [tile][split][lane][4] bf16, rows = head channels) and leaves partial sums [wave][head][cell] at out after the
-// barrier; the caller adds the waves up.
-template <class G, int CIN, int COUT, int MODE>
+// (hw: [tile][split][lane][4] bf16, rows = the NH head channels) and leaves partial sums [channel tile][head][cell] at out
+// after the barrier; the caller adds the channel tiles up.
+template <class G, int CIN, int COUT, int MODE, int NH = 6>
 __device__ __forceinline__ void conv_layer_bf3(const uint4 *in, void *out, const uint4 *__restrict__ wp, const uint4 (&w0)[3],
                                                const float (&bco)[4], const uint2 (&hw)[3], const unsigned short *wpos,
-                                               const unsigned short *cellof, int wave, int lane)
+                                               const unsigned short *cellof, int wave, int lane, f32x4 *keep = nullptr)
 {
     constexpr int NG = COUT / 16;              // channel tiles = wave columns
     constexpr int MG = (G::NW / NG) > 0 ? (G::NW / NG) : 1;
@@ -221,36 +226,40 @@ __device__ __forceinline__ void conv_layer_bf3(const uint4 *in, void *out, const
             for (int s = 0; s < 3; s++) wc[s] = wn[s];
         }
     }
-    if constexpr (MODE == BF3_OUT_HEADS) {
-        static_assert(MG == 1, "the fused head convs need all cell tiles of a channel tile in one wave");
+    // relu(acc + bias [+ skip]) of the wave's tiles
+    float v[MTW][4];
+#pragma unroll
+    for (int i = 0; i < MTW; i++) {
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            float x = acc[i][rg] + bco[rg];
+            if constexpr ((MODE & BF3_SKIP) != 0) x = x + keep[i][rg];
+            v[i][rg] = x > 0.0f ? x : 0.0f;
+        }
+        if constexpr ((MODE & BF3_KEEP) != 0) keep[i] = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
+    }
+    if constexpr ((MODE & BF3_OUT_HEADS) != 0) {
         f32x4 hacc[MTW];
 #pragma unroll
         for (int i = 0; i < MTW; i++) {
-            float v[4];
-#pragma unroll
-            for (int rg = 0; rg < 4; rg++) {
-                const float x = acc[i][rg] + bco[rg];
-                v[rg] = x > 0.0f ? x : 0.0f;
-            }
             uint2 xs[3];
-            split_bf3(v, xs);
+            split_bf3(v[i], xs);
             f32x4 h = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int p = 0; p < 6; p++) h = mfma_bf16k(hw[BF3_WS[p]], xs[BF3_AS[p]], h);
             hacc[i] = h;
         }
-        __syncthreads();                       // every wave has finished reading the conv3 input image: the partial sums overlay it
-        float *o = reinterpret_cast<float *>(out) + wave * 6 * G::MR;
-        // result rows = head channels: lanes q = 0 hold channels 0..3, q = 1 channels 4..5 (rows 6..15 are padding)
+        __syncthreads();                       // every wave has finished reading the input image: the partial sums overlay it
+        float *o = reinterpret_cast<float *>(out) + ng * NH * G::MR;
+        // result rows = head channels: lanes q = 0 hold channels 0..3, q = 1 channels 4..7 (rows NH..15 are padding)
 #pragma unroll
         for (int i = 0; i < MTW; i++) {
-            const int m = i * 16 + r16;
-            if (q == 0) {
+            const int mt = mg + i * MG;
+            if (mt < G::MT && q < 2) {
+                const int m = mt * 16 + r16;
 #pragma unroll
-                for (int rg = 0; rg < 4; rg++) o[rg * G::MR + m] = hacc[i][rg];
-            } else if (q == 1) {
-                o[4 * G::MR + m] = hacc[i][0];
-                o[5 * G::MR + m] = hacc[i][1];
+                for (int rg = 0; rg < 4; rg++)
+                    if (q * 4 + rg < NH) o[(q * 4 + rg) * G::MR + m] = hacc[i][rg];
             }
         }
     } else {
@@ -260,15 +269,7 @@ __device__ __forceinline__ void conv_layer_bf3(const uint4 *in, void *out, const
             const int mt = mg + i * MG;
             if (mt < G::MT) {
                 const int m = mt * 16 + r16;
-                if (cellof[m] != 0xFFFFu) {
-                    float v[4];
-#pragma unroll
-                    for (int rg = 0; rg < 4; rg++) {
-                        const float x = acc[i][rg] + bco[rg];
-                        v[rg] = x > 0.0f ? x : 0.0f;
-                    }
-                    store_bf3<G>(reinterpret_cast<uint2 *>(out), ng * 16 + q * 4, wpos[m], v);
-                }
+                if (cellof[m] != 0xFFFFu) store_bf3<G>(reinterpret_cast<uint2 *>(out), ng * 16 + q * 4, wpos[m], v[i]);
             }
         }
     }
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk_bf3(DevState d, NetWeights
     }
     __syncthreads();
     AZ_STAMP(1);
-    conv1_bf3<G>(inP, reinterpret_cast<uint2 *>(lds), pre, wpos, cellof, wave, lane);
+    conv_first_bf3<G, 32>(inP, reinterpret_cast<uint2 *>(lds), pre.c1w, pre.b1, wpos, cellof, wave, lane);
     bf3_weights<18>(reinterpret_cast<const uint4 *>(w.c3x), wave, 0, lane, w3);       // conv3's first K-block, a layer ahead
     __syncthreads();
     for (int i = tid; i < 3 * G::CS; i += NTH) inP[i] = 0.0f;      // plane 12 is part of conv2's output image
@@ -400,4 +401,153 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk_bf3(DevState d, NetWeights
         }
     }
     AZ_STAMP(5);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The ResidualBlock variant (BASELINE config 5; k_trunk_res in az_net.h) with the same emulation: stem on the f32 MFMA, the
+// six 64 -> 64 convs and the 1x1 heads on the bf16 MFMA.  ONE 64-channel split image (24 planes) serves every layer: a conv
+// keeps its result in accumulators until the barrier and writes it over its own input, and the skip connection's operand
+// x never needs LDS -- every conv gives a wave the same channel tile x cell tiles, so the wave keeps its tiles of x as
+// float32 registers (`keep`) from the epilogue that produced them to the epilogue that adds them (relu(conv2(h) + b + x)).
+// First K-block fragments and biases of layer l + 1 are requested before layer l runs.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(ResGeo<N>::NW * 64) void k_trunk_res_bf3(DevState d, ResWeights w, int net_id, float *__restrict__ feat)
+{
+    typedef ResGeo<N> G;
+    constexpr int NTH = G::NW * 64;
+    constexpr int NG = 4, MG = G::NW / NG, MTW = (G::MT + MG - 1) / MG, NH = G::PC + G::VC;
+    static_assert(100 * G::CS <= G::LDSF && NG * NH * G::MR <= 96 * G::CS, "LDS layout of the emulated ResidualBlock trunk");
+    __shared__ __attribute__((aligned(16))) float lds[G::LDSF];
+    __shared__ unsigned short wpos[G::MR];
+    __shared__ unsigned short cellof[G::MR];
+    __shared__ int any_active;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b0 = blockIdx.x * G::G;
+    const int ng = wave % NG, q = lane >> 4;
+    if (tid == 0) any_active = 0;
+    __syncthreads();
+    if (tid < G::G) {
+        const int b = b0 + tid;
+        if (b < d.B) {
+            const int kind = d.leaf_kind[b];
+            if (leaf_needs_net(kind) && d.s_status[b] == SLOT_ACTIVE && d.s_net[b] == net_id) atomicOr(&any_active, 1);
+        }
+    }
+    // requests that depend on nothing: stem fragments and bias, the first conv's first K-block and bias
+    float4 c1w[3];
+    float bcur[4], bnxt[4];
+    uint2 hw[3];
+    uint4 wcur[3], wnxt[3];
+    {
+        const float4 *c1 = reinterpret_cast<const float4 *>(w.stem) + (size_t)ng * 3 * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < 3; j++) c1w[j] = c1[j * 64];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) bcur[rg] = w.stemb[ng * 16 + q * 4 + rg];
+#pragma unroll
+        for (int s = 0; s < 3; s++) hw[s] = uint2{0u, 0u};
+        bf3_weights<18>(reinterpret_cast<const uint4 *>(w.blkx[0]), ng, 0, lane, wnxt);
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) bnxt[rg] = w.blkb[0][ng * 16 + q * 4 + rg];
+    }
+    // the 64-channel split image = 24 planes of CS slots (96 * CS floats); the stem's float32 input planes behind it
+    float *inP = lds + 96 * G::CS;
+    constexpr int EPT = (G::MR + NTH - 1) / NTH;
+    int e_pos[EPT];
+    bool e_me[EPT], e_op[EPT], e_last[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        const int m = tid + e * NTH;
+        int pos = G::PW + 1, cell = 0xFFFF;
+        if (m < G::MR) {
+            if constexpr (G::ROWT) {
+                const int t = m >> 4, c = m & 15, g = t / N, r = t - g * N;
+                pos = g * G::PP + (r + 1) * G::PW + (c + 1);
+                cell = c < N ? g * G::nn + r * N + c : 0xFFFF;
+            } else {
+                const int g = m / G::nn, p = m - g * G::nn, r = p / N, c = p - r * N;
+                pos = m < G::M ? g * G::PP + (r + 1) * G::PW + (c + 1) : G::PW + 1;
+                cell = m < G::M ? m : 0xFFFF;
+            }
+            wpos[m] = (unsigned short)pos;
+            cellof[m] = (unsigned short)cell;
+        }
+        e_pos[e] = pos;
+        e_me[e] = e_op[e] = e_last[e] = false;
+        if (cell != 0xFFFF) {
+            const int g = cell / G::nn, p = cell - g * G::nn;
+            const int b = b0 + g;
+            if (b < d.B) {
+                const u64 *lf = d.leaf + (size_t)b * 8;
+                e_me[e] = (lf[p >> 6] >> (p & 63)) & 1ull;            // games.py:86-129 encode
+                e_op[e] = (lf[4 + (p >> 6)] >> (p & 63)) & 1ull;
+                e_last[e] = d.leaf_last[b] == p;
+            }
+        }
+    }
+    {
+        float4 *z = reinterpret_cast<float4 *>(lds);
+        for (int i = tid; i < (100 * G::CS) / 4; i += NTH) z[i] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    if (!any_active) return;
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        if (e_me[e]) inP[e_pos[e]] = 1.0f;
+        if (e_op[e]) inP[G::CS + e_pos[e]] = 1.0f;
+        if (e_last[e]) inP[2 * G::CS + e_pos[e]] = 1.0f;
+    }
+    __syncthreads();
+    f32x4 keep[MTW];
+    const uint4 *X = reinterpret_cast<const uint4 *>(lds);
+    conv_first_bf3<G, 64>(inP, reinterpret_cast<uint2 *>(lds), c1w, bcur, wpos, cellof, wave, lane, keep);
+    __syncthreads();
+    // layer l's first K-block and bias were requested a layer ago (wnxt / bnxt); take them over and request layer l + 1's
+    auto advance = [&](int l) {
+#pragma unroll
+        for (int s = 0; s < 3; s++) wcur[s] = wnxt[s];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) bcur[rg] = bnxt[rg];
+        if (l + 1 < 6) {
+            bf3_weights<18>(reinterpret_cast<const uint4 *>(w.blkx[l + 1]), ng, 0, lane, wnxt);
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) bnxt[rg] = w.blkb[l + 1][ng * 16 + q * 4 + rg];
+        }
+    };
+#pragma unroll 1
+    for (int blk = 0; blk < 3; blk++) {
+        advance(2 * blk);           // block conv1: h = relu(bn1(conv1(x)))
+        conv_layer_bf3<G, 64, 64, BF3_OUT_IMAGE, NH>(X, lds, reinterpret_cast<const uint4 *>(w.blkx[2 * blk]), wcur, bcur, hw, wpos, cellof,
+                                                     wave, lane, keep);
+        __syncthreads();
+        advance(2 * blk + 1);
+        if (blk < 2) {              // block conv2: relu(bn2(conv2(h)) + x); the new x stays in registers as well
+            conv_layer_bf3<G, 64, 64, BF3_OUT_IMAGE | BF3_SKIP | BF3_KEEP, NH>(X, lds, reinterpret_cast<const uint4 *>(w.blkx[2 * blk + 1]), wcur,
+                                                                               bcur, hw, wpos, cellof, wave, lane, keep);
+        } else {                    // res3.conv2 + skip, then the 1x1 heads straight from the accumulators
+            const uint2 *hx = reinterpret_cast<const uint2 *>(w.hdx) + (size_t)ng * 3 * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < 3; s++) hw[s] = hx[s * 64];
+            conv_layer_bf3<G, 64, 64, BF3_OUT_HEADS | BF3_SKIP, NH>(X, lds, reinterpret_cast<const uint4 *>(w.blkx[5]), wcur, bcur, hw, wpos,
+                                                                    cellof, wave, lane, keep);
+        }
+        __syncthreads();
+    }
+    for (int o = tid; o < NH * G::MR; o += NTH) {
+        const int j = o / G::MR, m = o - j * G::MR;
+        const int cell = cellof[m];
+        if (cell != 0xFFFF) {
+            const int g = cell / G::nn, p = cell - g * G::nn;
+            const int b = b0 + g;
+            if (b < d.B && d.s_net[b] == net_id) {
+                float v = lds[o];
+#pragma unroll
+                for (int t = 1; t < NG; t++) v = v + lds[t * NH * G::MR + o];
+                v = v + w.hdb[j];
+                feat[(size_t)b * G::FROW + j * G::nn + p] = v > 0.0f ? v : 0.0f;      // 0-1 policy_conv, 2 value_conv
+            }
+        }
+    }
 }

@@ -293,6 +293,7 @@ def main():
             "episode": episode,
             "roofline": {"kernel": (f"k_search<{n},{persist}> (persistent: one launch per ply = {S + 1} x [encode+conv trunk+heads (MFMA), FC layers, tree step], "
                                     f"{persist} games per workgroup, trees in LDS; priced with the trunk FLOPs only)" if persist
+                                    else f"k_trunk_res_bf3<{n}> (encode+stem+3 residual blocks+head convs, LDS-resident; the 64->64 convs = 6 x v_mfma_f32_16x16x32_bf16 per tile and 32 k; peak = bf16 dense peak / 6)" if a.trunk != "f32" and a.model == "resnet"
                                     else f"k_trunk_bf3<{n}> (encode+conv1+conv2+conv3+head convs, LDS-resident; conv2/conv3 = 6 x v_mfma_f32_16x16x32_bf16 per tile and 32 k; peak = bf16 dense peak / 6)" if a.trunk != "f32"
                                     else f"k_trunk<{n}> (encode+conv1+conv2+conv3+head convs, LDS-resident, v_mfma_f32_16x16x4_f32)" if a.model == "plain"
                                     else f"k_trunk_res<{n}> (encode+stem+3 residual blocks+head convs, LDS-resident, v_mfma_f32_16x16x4_f32)"),

@@ -1,8 +1,10 @@
-"""GPU tests of the opt-in fp32-emulating conv trunk (az_set_trunk_mode(AZ_TRUNK_BF16X3), csrc/az_net_bf3.h).
+"""GPU tests of the opt-in fp32-emulating conv trunk (az_set_trunk_mode(AZ_TRUNK_BF16X3), csrc/az_net_bf3.h), GomokuNet and
+the ResidualBlock variant.
 
 The mode trades the canonical fp order (bit-exact against the oracle) for the bf16 matrix cores, so its bar is a
 tolerance, the one the build already grants against the Python reference's torch numbers:
-    |dlogit| <= 2e-5, |dP| <= 1e-6, |dvalue| <= 2e-6          (against the oracle's exact-order float32 forward)
+    |dlogit| <= 2e-5, |dP| <= 1e-6, |dvalue| <= 2e-6          (against the oracle's exact-order float32 forward;
+                                                               ResidualBlock net: |dvalue| <= 5e-6, its own torch bar)
 Everything integer stays exact given the evaluations: boards, legality, outcomes, z.  Visit counts CAN differ from the
 oracle's where two PUCT scores are closer than the evaluation error; the fraction of plies whose visit counts stay identical
 is measured, reported (gpurun_out/bf16x3_parity.json) and held above a floor.  The reference has no such mode: parity of
@@ -52,13 +54,25 @@ def _report(key, value):
         pass
 
 
-@pytest.mark.parametrize("n,k,tag", [(5, 4, "seeded"), (5, 4, "ckpt_saved"), (9, 5, "seeded"), (15, 5, "seeded")])
-def test_net_outputs_within_tolerance_of_the_oracle(n, k, tag):
+def _net(n, tag):
+    """(weights for the engine, oracle net, engine model kind): 'seeded' / 'ckpt_saved' = GomokuNet, 'resnet' = the
+    ResidualBlock variant (build-owned seeded weights; the oracle takes the BatchNorm-folded tensors)."""
+    if tag == "resnet":
+        from alphazero_piskvorky_amd.net import fold_resnet_state_dict
+        from alphazero_piskvorky_amd.weights import synthetic_resnet_state_dict
+        sd = synthetic_resnet_state_dict(n)
+        return sd, orc.Net(n, resnet_tensors=fold_resnet_state_dict(sd)), "resnet"
     sd = weights_from_fixture(n, tag)       # "ckpt_saved" = the reference's trained 5x5 checkpoint (values in the fixture)
+    return sd, orc.Net(n, sd), "plain"
+
+
+@pytest.mark.parametrize("n,k,tag", [(5, 4, "seeded"), (5, 4, "ckpt_saved"), (9, 5, "seeded"), (15, 5, "seeded"),
+                                     (5, 4, "resnet"), (9, 5, "resnet"), (15, 5, "resnet")])
+def test_net_outputs_within_tolerance_of_the_oracle(n, k, tag):
+    sd, onet, model = _net(n, tag)
     boards, players, lasts = _positions(n, 96, 7 + n)
     o = orc.Oracle(n, k, 1)
-    onet = orc.Net(n, sd)
-    e = az.Engine(n, k, 8, 40)          # 96 positions in three passes of 40 / 40 / 16 boards
+    e = az.Engine(n, k, 8, 40, model=model)          # 96 positions in three passes of 40 / 40 / 16 boards
     e.load_weights(sd, 0)
     l32, p32, v32 = e.net_eval(boards, players, lasts)
     e.set_trunk_mode("bf16x3")
@@ -77,22 +91,25 @@ def test_net_outputs_within_tolerance_of_the_oracle(n, k, tag):
         dp = max(dp, float(np.abs(pem[i] - Po.reshape(-1)).max()))
         dv = max(dv, float(abs(float(vem[i]) - float(vo))))
     _report(f"net_{n}x{n}_{tag}", {"max_abs_dlogit": dl, "max_abs_dP": dp, "max_abs_dvalue": dv, "positions": len(boards)})
+    # the ResidualBlock net's bar for the value is the one tests/test_resnet_gpu.py grants the exact-order kernel against the
+    # build's torch module (5e-6): seven stacked convs and a skip path instead of three convs
+    tol_v = 5e-6 if model == "resnet" else TOL_V
     assert dl <= TOL_LOGIT, f"|dlogit| {dl:.3e} > {TOL_LOGIT}"
     assert dp <= TOL_P, f"|dP| {dp:.3e} > {TOL_P}"
-    assert dv <= TOL_V, f"|dvalue| {dv:.3e} > {TOL_V}"
+    assert dv <= tol_v, f"|dvalue| {dv:.3e} > {tol_v}"
     assert dl > 0.0, "the emulated trunk returned the canonical bits: the mode switch did nothing"
 
 
-@pytest.mark.parametrize("n,k,S,G,maxply", [(9, 5, 200, 6, 0), (15, 5, 400, 4, 24)])
-def test_selfplay_in_emulated_mode_against_the_oracle(n, k, S, G, maxply):
+@pytest.mark.parametrize("n,k,S,G,maxply,tag", [(9, 5, 200, 6, 0, "seeded"), (15, 5, 400, 4, 24, "seeded"), (15, 5, 200, 3, 12, "resnet")])
+def test_selfplay_in_emulated_mode_against_the_oracle(n, k, S, G, maxply, tag):
     """Games played with the emulated trunk: rules, records and z exact; every ply searched again by the oracle (exact
     float32 order) from the recorded position with the same tape -- the fraction of plies whose visit counts are
     identical is reported and must stay above a floor; pi agrees within 1e-6 on those plies."""
     from concurrent.futures import ThreadPoolExecutor
     nn = n * n
     seed0 = 9100
-    sd = build_weights(n)
-    e = az.Engine(n, k, S, G, log_table=orc.numpy_log_table(S))
+    sd, onet, model = _net(n, tag)
+    e = az.Engine(n, k, S, G, log_table=orc.numpy_log_table(S), model=model)
     e.load_weights(sd, 0)
     e.set_trunk_mode("bf16x3")
     c = e.selfplay(G, seed0=seed0, max_plies=maxply)
@@ -101,7 +118,6 @@ def test_selfplay_in_emulated_mode_against_the_oracle(n, k, S, G, maxply):
     e.close()
     assert c["simulations"] == S * c["plies"] and c["expansions"] + c["terminal_hits"] == c["simulations"]
     o = orc.Oracle(n, k, S)
-    onet = orc.Net(n, sd)
     T = orc.selfplay_T_table(nn)
     jobs, off = [], 0
     for g in range(G):
@@ -136,21 +152,30 @@ def test_selfplay_in_emulated_mode_against_the_oracle(n, k, S, G, maxply):
                 max_dpi = max(max_dpi, float(np.abs(rec["pis"][ri] - r["pi"]).max()))
             same_action += int(rec["actions"][ri]) == r["action"]
     frac = same / total
-    _report(f"selfplay_{n}x{n}_S{S}", {"plies": total, "plies_with_identical_visit_counts": same, "fraction": frac,
+    _report(f"selfplay_{n}x{n}_S{S}_{tag}", {"plies": total, "plies_with_identical_visit_counts": same, "fraction": frac,
                                         "plies_with_identical_move": same_action, "max_abs_dpi_on_identical_plies": max_dpi})
-    print(f"bf16x3 {n}x{n} S={S}: {same}/{total} plies with visit counts identical to the exact-order oracle "
+    print(f"bf16x3 {tag} {n}x{n} S={S}: {same}/{total} plies with visit counts identical to the exact-order oracle "
           f"({frac:.3f}), same move on {same_action}, max |dpi| {max_dpi:.2e}")
     assert frac >= 0.75, f"only {same}/{total} plies kept the oracle's visit counts"
     assert max_dpi <= 1e-6
 
 
+def test_selfplay_manager_with_the_emulated_trunk():
+    """The drop-in seam: SelfPlayManager(trunk="bf16x3") returns the reference's (state, pi, z) contract."""
+    import torch
+    from alphazero_piskvorky_amd.controller import NeuralNetworkController
+    from alphazero_piskvorky_amd.net import GomokuNet
+    from alphazero_piskvorky_amd.self_play import SelfPlayManager
+    torch.manual_seed(0)
+    ctl = NeuralNetworkController(GomokuNet(board_size=5), device="cuda:0")
+    ex = SelfPlayManager(ctl, "cuda:0", mcts_params={"num_simulations": 20}, seed=5, trunk="bf16x3").generate_self_play(6)
+    assert len(ex) % 4 == 0 and len(ex) >= 6 * 4 * 7
+    st, pi, z = ex[0]
+    assert tuple(st.shape) == (4, 5, 5) and pi.shape == (5, 5) and z in (-1, 0, 1)
+    assert abs(float(pi.sum()) - 1.0) < 1e-5
+
+
 def test_mode_errors():
-    from alphazero_piskvorky_amd.weights import synthetic_resnet_state_dict
-    e = az.Engine(5, 4, 8, 2, model="resnet")
-    e.load_weights(synthetic_resnet_state_dict(5), 0)
-    with pytest.raises(_capi.AzError):
-        e.set_trunk_mode("bf16x3")          # GomokuNet only
-    e.close()
     e = az.Engine(5, 4, 8, 2)
     e.load_weights(build_weights(5), 0)
     with pytest.raises(_capi.AzError):
