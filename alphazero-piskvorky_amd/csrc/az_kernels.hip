@@ -16,7 +16,7 @@ void trunk(const LaunchCtx &c, int net_id)
     if (c.model == 1) {
         typedef ResGeo<N> G;
         dim3 gt((c.dv.B + G::G - 1) / G::G), bt(G::NW * 64);
-        if (c.emul) hipLaunchKernelGGL(k_trunk_res_bf3<N>, gt, bt, 0, c.stream, c.dv, c.rw[net_id], net_id, c.feat);
+        if (c.emul) hipLaunchKernelGGL(k_trunk_res_bf3<N>, gt, dim3(ResGeoBf3<N>::NW * 64), 0, c.stream, c.dv, c.rw[net_id], net_id, c.feat);
         else hipLaunchKernelGGL(k_trunk_res<N>, gt, bt, 0, c.stream, c.dv, c.rw[net_id], net_id, c.feat);
     } else {
         typedef NetGeo<N> G;

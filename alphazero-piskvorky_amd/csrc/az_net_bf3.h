@@ -411,10 +411,20 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk_bf3(DevState d, NetWeights
 // float32 registers (`keep`) from the epilogue that produced them to the epilogue that adds them (relu(conv2(h) + b + x)).
 // First K-block fragments and biases of layer l + 1 are requested before layer l runs.
 // ------------------------------------------------------------------------------------------------
+#ifndef AZ_RES_BF3_NW
+#define AZ_RES_BF3_NW 8       // waves per workgroup of the emulated ResidualBlock trunk (0 = as k_trunk_res: 12 at n = 15).  Measured at n = 15:
+                              // 8 waves (4 channel tiles x 2 cell groups of 8 / 7 tiles, 256 VGPRs) 107.3 us per 256 boards, 12 waves (x 3 groups
+                              // of 5, no surplus tile, 168 VGPRs and a 5-dword spill) 109.6 us
+#endif
 template <int N>
-__global__ __launch_bounds__(ResGeo<N>::NW * 64) void k_trunk_res_bf3(DevState d, ResWeights w, int net_id, float *__restrict__ feat)
+struct ResGeoBf3 : ResGeo<N> {
+    static constexpr int NW = AZ_RES_BF3_NW ? AZ_RES_BF3_NW : ResGeo<N>::NW;
+};
+
+template <int N>
+__global__ __launch_bounds__(ResGeoBf3<N>::NW * 64) void k_trunk_res_bf3(DevState d, ResWeights w, int net_id, float *__restrict__ feat)
 {
-    typedef ResGeo<N> G;
+    typedef ResGeoBf3<N> G;
     constexpr int NTH = G::NW * 64;
     constexpr int NG = 4, MG = G::NW / NG, MTW = (G::MT + MG - 1) / MG, NH = G::PC + G::VC;
     static_assert(100 * G::CS <= G::LDSF && NG * NH * G::MR <= 96 * G::CS, "LDS layout of the emulated ResidualBlock trunk");
