@@ -170,6 +170,12 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
     const float4 *wp4[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; t++) wp4[t] = reinterpret_cast<const float4 *>(wp) + (size_t)(nt_base + ng * NTW + t) * KS4 * 64 + lane;
+    // the epilogue's biases are requested before the main loop, so that their L2 round trip is not paid between two layers
+    float bias_pre[NTW][4];
+#pragma unroll
+    for (int t = 0; t < NTW; t++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) bias_pre[t][rg] = bias[(nt_base + ng * NTW + t) * 16 + q * 4 + rg];
     if constexpr (CIN == 4) {
         // conv1: 9 k-steps (one per tap), channels = {mover, opponent, last move, zero plane}, planes [ci][pos]
         int rb[MTW];
@@ -262,7 +268,7 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
         const int nt = nt_base + ng * NTW + t;
         float bco[4];
 #pragma unroll
-        for (int rg = 0; rg < 4; rg++) bco[rg] = bias[nt * 16 + q * 4 + rg];
+        for (int rg = 0; rg < 4; rg++) bco[rg] = bias_pre[t][rg];
 #pragma unroll
         for (int i = 0; i < MTW; i++) {
             const int mt = mg + i * MG;
@@ -366,47 +372,55 @@ __device__ __forceinline__ void trunk_group(const DevState &d, const NetWeights 
                 atomicOr(&any_active, 1);
         }
     }
-    __syncthreads();
-    if (!any_active) return;
-
     float *inA = lds;                  // 32 channels (conv1 out / conv2 in)
     float *inB = lds + 32 * G::CS;     // 64 channels (conv2 out / conv3 in); first 4 channels hold the input planes
-    // zero both padded images (the padding ring must read as 0)
-    {
-        float4 *z = reinterpret_cast<float4 *>(lds);
-        for (int i = tid; i < (96 * G::CS) / 4; i += AZ_NW * 64) z[i] = float4{0.f, 0.f, 0.f, 0.f};
-    }
-    for (int m = tid; m < G::MR; m += AZ_NW * 64) {
-        int pos, cell;
-        if constexpr (G::ROWT) {
-            const int t = m >> 4, c = m & 15, g = t / N, r = t - g * N;
-            pos = g * G::PP + (r + 1) * G::PW + (c + 1);                 // c == N is the right padding cell of the row
-            cell = c < N ? g * G::nn + r * N + c : 0xFFFF;
-        } else {
-            const int g = m / G::nn, p = m - g * G::nn, r = p / N, c = p - r * N;
-            pos = m < G::M ? g * G::PP + (r + 1) * G::PW + (c + 1) : G::PW + 1;
-            cell = m < G::M ? m : 0xFFFF;
+    // Every thread requests the leaf words of its cells (games.py:86-129 encode: ch0 = side to move, ch1 = opponent, ch2 = last
+    // action, ch3 = zeros) before it is known whether the group has anything to evaluate: the loads are in flight while both
+    // padded images are zeroed (the padding ring must read as 0).
+    constexpr int EPT = (G::MR + AZ_NW * 64 - 1) / (AZ_NW * 64);
+    int e_pos[EPT];
+    bool e_me[EPT], e_op[EPT], e_last[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        const int m = tid + e * AZ_NW * 64;
+        int pos = G::PW + 1, cell = 0xFFFF;
+        if (m < G::MR) {
+            if constexpr (G::ROWT) {
+                const int t = m >> 4, c = m & 15, g = t / N, r = t - g * N;
+                pos = g * G::PP + (r + 1) * G::PW + (c + 1);                 // c == N is the right padding cell of the row
+                cell = c < N ? g * G::nn + r * N + c : 0xFFFF;
+            } else {
+                const int g = m / G::nn, p = m - g * G::nn, r = p / N, c = p - r * N;
+                pos = m < G::M ? g * G::PP + (r + 1) * G::PW + (c + 1) : G::PW + 1;
+                cell = m < G::M ? m : 0xFFFF;
+            }
+            wpos[m] = (unsigned short)pos;
+            cellof[m] = (unsigned short)cell;
         }
-        wpos[m] = (unsigned short)pos;
-        cellof[m] = (unsigned short)cell;
-    }
-    __syncthreads();
-    // games.py:86-129 encode: ch0 = side to move, ch1 = opponent, ch2 = last action, ch3 = zeros
-    for (int m = tid; m < G::MR; m += AZ_NW * 64) {
-        const int cell = cellof[m];
+        e_pos[e] = pos;
+        e_me[e] = e_op[e] = e_last[e] = false;
         if (cell != 0xFFFF) {
             const int g = cell / G::nn, p = cell - g * G::nn;
             const int b = b0 + g;
             if (b < d.B) {
                 const u64 *lf = d.leaf + (size_t)b * 8;
-                const bool me = (lf[p >> 6] >> (p & 63)) & 1ull;
-                const bool op = (lf[4 + (p >> 6)] >> (p & 63)) & 1ull;
-                const int pos = wpos[m];
-                if (me) inB[pos] = 1.0f;
-                if (op) inB[G::CS + pos] = 1.0f;
-                if (d.leaf_last[b] == p) inB[2 * G::CS + pos] = 1.0f;
+                e_me[e] = (lf[p >> 6] >> (p & 63)) & 1ull;
+                e_op[e] = (lf[4 + (p >> 6)] >> (p & 63)) & 1ull;
+                e_last[e] = d.leaf_last[b] == p;
             }
         }
+    }
+    {
+        float4 *z = reinterpret_cast<float4 *>(lds);
+        for (int i = tid; i < (96 * G::CS) / 4; i += AZ_NW * 64) z[i] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    if (!any_active) return;
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        if (e_me[e]) inB[e_pos[e]] = 1.0f;
+        if (e_op[e]) inB[G::CS + e_pos[e]] = 1.0f;
+        if (e_last[e]) inB[2 * G::CS + e_pos[e]] = 1.0f;
     }
     __syncthreads();
     AZ_STAMP(1);
