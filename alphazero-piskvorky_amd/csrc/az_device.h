@@ -197,6 +197,37 @@ __device__ __forceinline__ bool wins_through(const Plane &me, int a, int n, int 
     return win;
 }
 
+// ---------------------------------------------------------------------------------------
+// dihedral symmetries of the board: k < 4 = np.rot90 k times (counter-clockwise), k >= 4 = rot90(fliplr(x), k - 4)
+// (games.py:183-197 rot90 / flip).  sym_src: source cell of output cell (i, j), i.e. sym(x)[i][j] = x[sym_src(k, i, j)].
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int sym_src(int k, int i, int j, int n)
+{
+    int si, sj;
+    switch (k & 3) {
+    case 0: si = i; sj = j; break;
+    case 1: si = j; sj = n - 1 - i; break;
+    case 2: si = n - 1 - i; sj = n - 1 - j; break;
+    default: si = n - 1 - j; sj = i; break;
+    }
+    if (k >= 4) sj = n - 1 - sj;
+    return si * n + sj;
+}
+__device__ __forceinline__ int sym_inverse(int k) { return k < 4 ? ((4 - k) & 3) : k; }    // the reflections are involutions
+// Opt-in random-symmetry leaf evaluation (az_set_leaf_symmetry): which of the 8 symmetries evaluation `idx` (0 = the root,
+// s + 1 = simulation s) of the search of `game` at `ply` shows to the net.  Same hash in the oracle (orc_leaf_sym).
+__device__ __forceinline__ int leaf_sym_of(int game, int ply, int idx)
+{
+    return (int)(az_fmix32((unsigned)game * 0x9E3779B1u ^ az_fmix32((unsigned)ply * 0x85EBCA6Bu + (unsigned)idx + 1u)) & 7u);
+}
+// board cell whose stone the net sees at image cell p (p itself without the option)
+__device__ __forceinline__ int sym_cell(const int *leaf_sym, int item, int p, int n)
+{
+    if (!leaf_sym) return p;
+    const int i = p / n;
+    return sym_src(leaf_sym[item], i, p - i * n, n);
+}
+
 // The same test done by the 64 lanes of a wavefront together (every lane must be active and hold the same plane and a):
 // lane = 16 * direction + 8 * side + (s - 1) probes the cell s steps from a along that direction and side; one ballot
 // gathers the 64 probes, and the run through a is counted with count-trailing-zero on the inverted 8-bit groups.  Replaces

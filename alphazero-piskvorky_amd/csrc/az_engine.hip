@@ -48,7 +48,7 @@ struct Lane {
     DevState d{};                  // the games' view (B = slots of this lane)
     DevState dv{};                 // the net kernels' view (B = evaluation items = slots x leaves per batch)
     DevBuf board, s_game, s_ply, s_player, s_last, s_status, s_net, edges, rows_used, cnt, active_dev, carried;   // per slot
-    DevBuf path, depth, leaf_kind, leaf, leaf_last, logits, vhid, pol_feat, dbg, scratch, it_status, it_net;       // per evaluation item
+    DevBuf path, depth, leaf_kind, leaf, leaf_last, logits, vhid, pol_feat, dbg, scratch, it_status, it_net, leaf_sym;       // per evaluation item
     // one ply (k_begin, (S+1) x {trunk, fc, step}, k_move) captured once as a hipGraph and replayed every ply:
     // 3(S+1)+2 launches (6(S+1)+2 with the split trunk) become one submission.  Indexed [split trunk][arena].
     struct PlyGraph {
@@ -83,6 +83,7 @@ struct az_engine {
     int vl = 1;                    // leaves per game and evaluation batch (az_set_virtual_loss); 1 = the reference's sequential loop
     bool vl_kernel = false;        // the batched tree kernel is in use (vl > 1, or AZ_VL_FORCE=1 to run it with batches of one)
     bool persist_allowed = true;   // AZ_PERSIST=0: never use the persistent search kernel
+    int leaf_symmetry = 0;         // az_set_leaf_symmetry: every evaluation shows the net a pseudo-random dihedral symmetry of the position
     int trunk_mode = AZ_TRUNK_F32; // az_set_trunk_mode: AZ_TRUNK_BF16X3 = conv2 / conv3 on the bf16 MFMA, three-way split operands
     int persist_gp = 0;            // games per workgroup of the persistent search kernel for the open episode, 0 = lock-step pipeline
     DevBuf cache;                  // evaluation cache shared by the lanes (az_set_eval_cache)
@@ -354,21 +355,6 @@ __global__ void k_pack(DevState d, const int *src_index, int64_t records, int nn
     }
 }
 
-// source cell of output cell (i, j) under symmetry k of the dihedral group: k<4 = np.rot90 k times (CCW),
-// k>=4 = rot90(fliplr(x), k-4)
-__device__ __forceinline__ int sym_src(int k, int i, int j, int n)
-{
-    int si, sj;
-    switch (k & 3) {
-    case 0: si = i; sj = j; break;
-    case 1: si = j; sj = n - 1 - i; break;
-    case 2: si = n - 1 - i; sj = n - 1 - j; break;
-    default: si = n - 1 - j; sj = i; break;
-    }
-    if (k >= 4) sj = n - 1 - sj;
-    return si * n + sj;
-}
-
 __global__ void k_examples(const unsigned char *packed, int64_t records, int n, int64_t rb, int aug, float *states,
                            float *pis, float *zs)
 {
@@ -479,7 +465,7 @@ static int alloc_items(az_engine *e, Lane &L, int leaves)
 #define ALLOC(buf, bytes) if (!rc) rc = dev_alloc(e, L.buf, (bytes))
     ALLOC(path, (NI * (size_t)e->PATH + 64) * 4);   // +64: k_step's speculative path[lane] read of the last slot
     ALLOC(depth, NI * 4);
-    ALLOC(leaf_kind, NI * 4); ALLOC(leaf, NI * 8 * sizeof(u64)); ALLOC(leaf_last, NI * 4);
+    ALLOC(leaf_kind, NI * 4); ALLOC(leaf, NI * 8 * sizeof(u64)); ALLOC(leaf_last, NI * 4); ALLOC(leaf_sym, NI * 4);
     ALLOC(logits, NI * (size_t)e->RW * 4); ALLOC(vhid, NI * 64 * 4);
     ALLOC(pol_feat, NI * (size_t)((((e->cfg.model == AZ_MODEL_RESNET ? 3 : 6) * e->nn + 3) / 4) * 4) * 4);   // feature rows [NI][FROW], zero tail stays zero
 #ifdef AZ_STAMPS
@@ -494,6 +480,7 @@ static int alloc_items(az_engine *e, Lane &L, int leaves)
     d.L = leaves;
     d.path = (unsigned *)L.path.p; d.depth = (int *)L.depth.p; d.leaf_kind = (int *)L.leaf_kind.p; d.leaf = (u64 *)L.leaf.p;
     d.leaf_last = (int *)L.leaf_last.p; d.logits = (float *)L.logits.p; d.vhid = (float *)L.vhid.p;
+    d.leaf_sym = e->leaf_symmetry ? (int *)L.leaf_sym.p : nullptr;
     d.it_status = leaves > 1 ? (int *)L.it_status.p : d.s_status;
     d.it_net = leaves > 1 ? (int *)L.it_net.p : d.s_net;
     return AZ_OK;
@@ -576,7 +563,7 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
         d.cnt = (unsigned long long *)L.cnt.p; d.active = (int *)L.active_dev.p;
         d.carried = (int *)L.carried.p; d.reuse = 0;
         d.v2w[0] = d.v2w[1] = d.v2b[0] = d.v2b[1] = nullptr;
-        d.cache = nullptr; d.cache_mask = 0; d.cache_gen = e->cache_gen; d.ext_eval = 0;
+        d.cache = nullptr; d.cache_mask = 0; d.cache_gen = e->cache_gen; d.ext_eval = 0; d.leaf_sym = nullptr;
         if (!rc) rc = alloc_items(e, L, 1);
     }
     if (!rc) rc = dev_alloc(e, e->next_game, 16);
@@ -633,7 +620,7 @@ extern "C" void az_destroy(az_engine *e)
     for (Lane &L : e->lanes) {
         DevBuf *all[] = {&L.board, &L.s_game, &L.s_ply, &L.s_player, &L.s_last, &L.s_status, &L.s_net, &L.edges, &L.rows_used,
                          &L.path, &L.depth, &L.leaf_kind, &L.leaf, &L.leaf_last, &L.logits, &L.vhid, &L.pol_feat, &L.cnt,
-                         &L.active_dev, &L.carried, &L.dbg, &L.scratch, &L.it_status, &L.it_net};
+                         &L.active_dev, &L.carried, &L.dbg, &L.scratch, &L.it_status, &L.it_net, &L.leaf_sym};
         for (DevBuf *b : all) dev_free(*b);
         for (hipEvent_t ev : L.ev) (void)hipEventDestroy(ev);
         for (int i = 0; i < 4; i++)
@@ -810,7 +797,8 @@ static int episode_begin(az_engine *e, const EpisodeSpec &sp)
     });
     // persistent search kernel: plain net or synthetic evaluator, the reference's sequential search, trees that fit into LDS
     e->persist_gp = 0;
-    if (e->persist_allowed && e->cfg.model == AZ_MODEL_PLAIN && !e->vl_kernel && !e->reuse && !e->cache.p && e->trunk_mode == AZ_TRUNK_F32) {
+    if (e->persist_allowed && e->cfg.model == AZ_MODEL_PLAIN && !e->vl_kernel && !e->reuse && !e->cache.p && e->trunk_mode == AZ_TRUNK_F32 &&
+        !e->leaf_symmetry) {
         const int synth = e->cfg.eval_kind == AZ_EVAL_SYNTHETIC ? 1 : 0;
         const int S = e->cfg.num_simulations;
         if (!sp.arena && !sp.preset && e->ops->search_prepare(S, 2, synth)) e->persist_gp = 2;
@@ -1338,7 +1326,8 @@ extern "C" int az_net_eval(az_engine *e, int slot, int count, const uint8_t *boa
         if (hr == hipSuccess) hr = az_memcpy(e->stream, L.leaf_last.p, ll.data(), (size_t)B * 4, hipMemcpyHostToDevice);
         if (hr != hipSuccess) { rc = fail(e, AZ_ERR_HIP, "az_net_eval upload: %s", hipGetErrorString(hr)); break; }
         {
-            const LaunchCtx lc = ctx_of_impl(e, L);
+            LaunchCtx lc = ctx_of_impl(e, L);
+            lc.d.leaf_sym = lc.dv.leaf_sym = nullptr;       // controller.py:39-53 evaluates the position as it is
             if (e->split_max > 0 && L.scratch.p && cnt <= e->split_max && e->trunk_mode == AZ_TRUNK_F32) e->ops->trunk_split(lc, slot); else e->ops->trunk(lc, slot);
             e->ops->fc(lc, slot);
             e->ops->eval_tail(lc, cnt, (float *)dpol.p, (float *)dval.p);
@@ -1531,6 +1520,7 @@ extern "C" int az_set_subtree_reuse(az_engine *e, int on)
     if (!e) return AZ_ERR_INVALID;
     if (e->run.open) return fail(e, AZ_ERR_STATE, "az_set_subtree_reuse: an episode is open");
     if (on && e->vl > 1) return fail(e, AZ_ERR_INVALID, "subtree reuse and virtual-loss batching cannot be combined");
+    if (on && e->leaf_symmetry) return fail(e, AZ_ERR_INVALID, "subtree reuse and random-symmetry leaf evaluation cannot be combined");
     if (on && e->R > REUSE_MAX_ROWS)
         return fail(e, AZ_ERR_INVALID, "subtree reuse supports at most %d simulations per move", REUSE_MAX_ROWS - 1);
     e->reuse = on ? 1 : 0;
@@ -1559,6 +1549,7 @@ extern "C" int az_set_virtual_loss(az_engine *e, int leaves)
     if (e->run.open) return fail(e, AZ_ERR_STATE, "az_set_virtual_loss: an episode is open");
     if (leaves < 1 || leaves > VL_MAX) return fail(e, AZ_ERR_INVALID, "virtual-loss batching supports 1..%d leaves per batch", VL_MAX);
     if (leaves > 1 && e->reuse) return fail(e, AZ_ERR_INVALID, "subtree reuse and virtual-loss batching cannot be combined");
+    if (leaves > 1 && e->leaf_symmetry) return fail(e, AZ_ERR_INVALID, "virtual-loss batching and random-symmetry leaf evaluation cannot be combined");
     DEVICE_GUARD(e);
     if (leaves != e->vl) {
         for (Lane &L : e->lanes) {
@@ -1581,6 +1572,7 @@ extern "C" int az_set_eval_cache(az_engine *e, int64_t entries)
     if (!e) return AZ_ERR_INVALID;
     if (e->run.open) return fail(e, AZ_ERR_STATE, "az_set_eval_cache: an episode is open");
     if (entries < 0 || entries > ((int64_t)1 << 26)) return fail(e, AZ_ERR_INVALID, "cache entries must be 0 (off) .. 2^26");
+    if (entries > 0 && e->leaf_symmetry) return fail(e, AZ_ERR_INVALID, "the evaluation cache and random-symmetry leaf evaluation cannot be combined");
     DEVICE_GUARD(e);
     if (entries == 0) {
         dev_free(e->cache);
@@ -1597,6 +1589,19 @@ extern "C" int az_set_eval_cache(az_engine *e, int64_t entries)
     }
     e->cache_gen++;
     each_state(e, [&](DevState &d) { d.cache = (float *)e->cache.p; d.cache_mask = e->cache_mask; d.cache_gen = e->cache_gen; });
+    return AZ_OK;
+}
+
+extern "C" int az_set_leaf_symmetry(az_engine *e, int on)
+{
+    if (!e) return AZ_ERR_INVALID;
+    if (e->run.open) return fail(e, AZ_ERR_STATE, "az_set_leaf_symmetry: an episode is open");
+    if (on && (e->vl > 1 || e->reuse || e->cache.p))
+        return fail(e, AZ_ERR_INVALID, "random-symmetry leaf evaluation cannot be combined with virtual-loss batching, subtree reuse or the evaluation cache");
+    if (on && e->cfg.eval_kind != AZ_EVAL_NET) return fail(e, AZ_ERR_INVALID, "random-symmetry leaf evaluation needs the net evaluator");
+    e->leaf_symmetry = on ? 1 : 0;
+    for (Lane &L : e->lanes) L.d.leaf_sym = on ? (int *)L.leaf_sym.p : nullptr;
+    each_state(e, [&](DevState &d) { (void)d; });        // refresh the item views
     return AZ_OK;
 }
 
@@ -1627,7 +1632,8 @@ extern "C" int az_search_callback(az_engine *e, const uint8_t *board, int player
 {
     if (!e || !board || !fn || (player != 1 && player != 2)) return fail(e, AZ_ERR_INVALID, "az_search_callback: bad argument");
     if (e->run.open) return fail(e, AZ_ERR_STATE, "az_search_callback: a self-play episode is open on this engine");
-    if (e->vl > 1 || e->reuse) return fail(e, AZ_ERR_INVALID, "az_search_callback: not combinable with virtual-loss batching or subtree reuse");
+    if (e->vl > 1 || e->reuse || e->leaf_symmetry)
+        return fail(e, AZ_ERR_INVALID, "az_search_callback: not combinable with virtual-loss batching, subtree reuse or random-symmetry leaf evaluation");
     DEVICE_GUARD(e);
     const int nn = e->nn, S = e->cfg.num_simulations;
     int stones = 0;

@@ -404,9 +404,10 @@ __device__ __forceinline__ void trunk_group(const DevState &d, const NetWeights 
             const int b = b0 + g;
             if (b < d.B) {
                 const u64 *lf = d.leaf + (size_t)b * 8;
-                e_me[e] = (lf[p >> 6] >> (p & 63)) & 1ull;
-                e_op[e] = (lf[4 + (p >> 6)] >> (p & 63)) & 1ull;
-                e_last[e] = d.leaf_last[b] == p;
+                const int ps = sym_cell(d.leaf_sym, b, p, N);
+                e_me[e] = (lf[ps >> 6] >> (ps & 63)) & 1ull;
+                e_op[e] = (lf[4 + (ps >> 6)] >> (ps & 63)) & 1ull;
+                e_last[e] = d.leaf_last[b] == ps;
             }
         }
     }
@@ -551,9 +552,10 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_split(DevState d, NetWeights w, 
                 if (b < d.B) {
                     const u64 *lf = d.leaf + (size_t)b * 8;
                     const int pos = wpos[m];
-                    if ((lf[p >> 6] >> (p & 63)) & 1ull) lds[pos] = 1.0f;
-                    if ((lf[4 + (p >> 6)] >> (p & 63)) & 1ull) lds[G::CS + pos] = 1.0f;
-                    if (d.leaf_last[b] == p) lds[2 * G::CS + pos] = 1.0f;
+                    const int ps = sym_cell(d.leaf_sym, b, p, G::n);
+                    if ((lf[ps >> 6] >> (ps & 63)) & 1ull) lds[pos] = 1.0f;
+                    if ((lf[4 + (ps >> 6)] >> (ps & 63)) & 1ull) lds[G::CS + pos] = 1.0f;
+                    if (d.leaf_last[b] == ps) lds[2 * G::CS + pos] = 1.0f;
                 }
             }
         }
@@ -671,9 +673,10 @@ __global__ __launch_bounds__(ResGeo<N>::NW * 64) void k_trunk_res(DevState d, Re
             if (b < d.B) {
                 const u64 *lf = d.leaf + (size_t)b * 8;
                 const int pos = wpos[m];
-                if ((lf[p >> 6] >> (p & 63)) & 1ull) B[pos] = 1.0f;
-                if ((lf[4 + (p >> 6)] >> (p & 63)) & 1ull) B[G::CS + pos] = 1.0f;
-                if (d.leaf_last[b] == p) B[2 * G::CS + pos] = 1.0f;
+                const int ps = sym_cell(d.leaf_sym, b, p, N);
+                if ((lf[ps >> 6] >> (ps & 63)) & 1ull) B[pos] = 1.0f;
+                if ((lf[4 + (ps >> 6)] >> (ps & 63)) & 1ull) B[G::CS + pos] = 1.0f;
+                if (d.leaf_last[b] == ps) B[2 * G::CS + pos] = 1.0f;
             }
         }
     }
@@ -803,9 +806,10 @@ __global__ __launch_bounds__(ResGeo<N>::NW * 64) void k_split_res(DevState d, co
                 if (b < d.B) {
                     const u64 *lf = d.leaf + (size_t)b * 8;
                     const int pos = wpos[m];
-                    if ((lf[p >> 6] >> (p & 63)) & 1ull) lds[pos] = 1.0f;
-                    if ((lf[4 + (p >> 6)] >> (p & 63)) & 1ull) lds[G::CS + pos] = 1.0f;
-                    if (d.leaf_last[b] == p) lds[2 * G::CS + pos] = 1.0f;
+                    const int ps = sym_cell(d.leaf_sym, b, p, G::n);
+                    if ((lf[ps >> 6] >> (ps & 63)) & 1ull) lds[pos] = 1.0f;
+                    if ((lf[4 + (ps >> 6)] >> (ps & 63)) & 1ull) lds[G::CS + pos] = 1.0f;
+                    if (d.leaf_last[b] == ps) lds[2 * G::CS + pos] = 1.0f;
                 }
             }
         }

@@ -351,9 +351,10 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk_bf3(DevState d, NetWeights
             const int b = b0 + g;
             if (b < d.B) {
                 const u64 *lf = d.leaf + (size_t)b * 8;
-                e_me[e] = (lf[p >> 6] >> (p & 63)) & 1ull;
-                e_op[e] = (lf[4 + (p >> 6)] >> (p & 63)) & 1ull;
-                e_last[e] = d.leaf_last[b] == p;
+                const int ps = sym_cell(d.leaf_sym, b, p, N);
+                e_me[e] = (lf[ps >> 6] >> (ps & 63)) & 1ull;
+                e_op[e] = (lf[4 + (ps >> 6)] >> (ps & 63)) & 1ull;
+                e_last[e] = d.leaf_last[b] == ps;
             }
         }
     }
@@ -491,9 +492,10 @@ __global__ __launch_bounds__(ResGeoBf3<N>::NW * 64) void k_trunk_res_bf3(DevStat
             const int b = b0 + g;
             if (b < d.B) {
                 const u64 *lf = d.leaf + (size_t)b * 8;
-                e_me[e] = (lf[p >> 6] >> (p & 63)) & 1ull;            // games.py:86-129 encode
-                e_op[e] = (lf[4 + (p >> 6)] >> (p & 63)) & 1ull;
-                e_last[e] = d.leaf_last[b] == p;
+                const int ps = sym_cell(d.leaf_sym, b, p, N);
+                e_me[e] = (lf[ps >> 6] >> (ps & 63)) & 1ull;          // games.py:86-129 encode
+                e_op[e] = (lf[4 + (ps >> 6)] >> (ps & 63)) & 1ull;
+                e_last[e] = d.leaf_last[b] == ps;
             }
         }
     }

@@ -78,6 +78,7 @@ struct DevState {
     // --- opt-in virtual-loss batching (the reference's TODO, mcts.py:17-22): L leaves per game and evaluation batch ---
     int L;                 // 1 = the reference's sequential simulation loop (mcts.py:123-141)
     int *it_status, *it_net;   // [B*L] per evaluation item, what the net kernels read as s_status / s_net (alias them when L == 1)
+    int *leaf_sym;         // [B] opt-in random-symmetry leaf evaluation (az_set_leaf_symmetry): symmetry 0..7 the net sees the pending leaf in; nullptr = off
     int ext_eval;          // the pending rows were filled by an evaluator outside the engine (az_search_callback): priors and value as given
 };
 
@@ -271,6 +272,7 @@ __global__ void k_begin(DevState d)
         lf[4 + i] = pl == 1 ? bd[4 + i] : bd[i];
     }
     d.leaf_last[it] = d.s_last[b];
+    if (d.leaf_sym) d.leaf_sym[it] = leaf_sym_of(d.s_game[b], d.s_ply[b], 0);
     d.leaf_kind[it] = (d.reuse && d.carried[b] >= 0) ? LEAF_REUSE : LEAF_ROOT;
     d.depth[it] = 0;
     const int netid = d.arena ? (pl == 1 ? 0 : 1) : 0;   // evaluator.py:73-79: each side searches with its own net
@@ -321,8 +323,18 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
     float h_l = 0.0f, w2a = 0.0f, w2b = 0.0f, b2a = 0.0f, b2b = 0.0f;
     if (!SYNTH) {
         const float *lg = d.logits + (size_t)bb * G::RW;
+        if (d.leaf_sym) {
+            // the net saw the leaf under symmetry t: board cell j sits at image cell sym_src(t^-1, j)
+            const int ti = sym_inverse(d.leaf_sym[bb]);
 #pragma unroll
-        for (int i = 0; i < G::CPL; i++) x[i] = lg[lane + 64 * i];
+            for (int i = 0; i < G::CPL; i++) {
+                const int j = lane + 64 * i, r = j / N;
+                x[i] = j < G::nn ? lg[sym_src(ti, r, j - r * N, N)] : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < G::CPL; i++) x[i] = lg[lane + 64 * i];
+        }
         h_l = d.vhid[(size_t)bb * 64 + lane];
         if (d.v2w[0]) { w2a = d.v2w[0][lane]; b2a = d.v2b[0][0]; }
         if (d.v2w[1]) { w2b = d.v2w[1][lane]; b2b = d.v2b[1][0]; }
@@ -535,6 +547,7 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
         d.leaf_last[b] = last;
         d.leaf_kind[b] = out_kind;
         d.depth[b] = depth;
+        if (d.leaf_sym) d.leaf_sym[b] = leaf_sym_of(game, ply, rootN + 1);     // this leaf is evaluation rootN + 1 of the search
     }
 }
 

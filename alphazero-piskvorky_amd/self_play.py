@@ -22,7 +22,7 @@ class SelfPlayManager:
                  temperature_schedule: Callable[[int], float] = default_temperature_schedule,
                  concurrent_games: int = None, augmentation: int = AZ_AUG_REFERENCE4, seed: int = None,
                  engines_per_gpu: int = None, subtree_reuse: bool = False, gather_to: int = None,
-                 eval_cache: int = 0, virtual_loss: int = 1, trunk: str = "f32"):
+                 eval_cache: int = 0, virtual_loss: int = 1, trunk: str = "f32", leaf_symmetry: bool = False):
         self.controller = controller
         self.device = device
         self.mcts_params = mcts_params or {"num_simulations": 100}
@@ -35,6 +35,7 @@ class SelfPlayManager:
         self.eval_cache = eval_cache          # opt-in: positions kept in the device evaluation cache (mcts.py:17,22 TODO); results unchanged
         self.virtual_loss = virtual_loss      # opt-in: leaves per search and evaluation batch (mcts.py:17-22 TODO); 1 = sequential like the reference
         self.trunk = trunk                    # opt-in: "bf16x3" = fp32-emulating conv trunk on the bf16 matrix cores (tolerance, not bit-exact)
+        self.leaf_symmetry = leaf_symmetry    # opt-in: every net evaluation sees a pseudo-random dihedral symmetry of the position (README.md:61,82)
         self.gather_to = gather_to            # multi-rank: None = every rank receives all records (all-gather); r = only rank r does
         self.last_counters = None
         self._engine = None
@@ -43,7 +44,7 @@ class SelfPlayManager:
         p = self.mcts_params
         key = (n, k, p.get("num_simulations", 100), slots, p.get("c_puct", _c.SELF_PLAY_EXPLORATION_CONSTANT),
                p.get("dirichlet_alpha", 0.3), p.get("dirichlet_weight", 0.25), model_kind(self.controller.net),
-               self.virtual_loss, self.eval_cache)
+               self.virtual_loss, self.eval_cache, self.leaf_symmetry)
         if self._engine is None or self._engine_key != key:
             if self._engine is not None:
                 self._engine.close()
@@ -53,6 +54,7 @@ class SelfPlayManager:
                                   log_table=numpy_log_table(key[2]), model=key[7])
             self._engine.set_virtual_loss(self.virtual_loss)
             self._engine.set_eval_cache(self.eval_cache)
+            self._engine.set_leaf_symmetry(self.leaf_symmetry)
             self._engine_key = key
         return self._engine
 

@@ -263,6 +263,18 @@ int az_set_virtual_loss(az_engine *e, int leaves);
  * bytes each.  Hits are reported in az_counters.cache_lookups / cache_hits.  Not allowed while an episode is open. */
 int az_set_eval_cache(az_engine *e, int64_t entries);
 
+/* Opt-in: random-symmetry leaf evaluation, the optional half of SURVEY §8f-2 (the reference's README.md:61,82 names the 8-fold
+ * symmetry of the board, its code only uses it to augment the examples and leaves Gomoku.rot90 / flip unused,
+ * games.py:183-197).  With it every net evaluation of a search -- the root (mcts.py:109) and each expanded leaf
+ * (mcts.py:137) -- shows the net one of the 8 dihedral symmetries of the position and maps the policy back: priors of a
+ * board cell = softmax entry of the image cell it was moved to; the value is taken as is.  The symmetry of evaluation idx
+ * (0 = root, s + 1 = simulation s) of game g at ply p is a fixed hash of (g, p, idx), so runs are reproducible and
+ * independent of slots, lanes and ranks.  Visit counts differ from the reference's (its net always sees the position
+ * unrotated); parity is against the oracle's restatement of this rule (orc_cfg.leaf_sym, "parity unpinned" by the
+ * reference).  Lock-step pipeline only; not combinable with virtual-loss batching, subtree reuse, the evaluation cache or
+ * az_search_callback.  Not allowed while an episode is open. */
+int az_set_leaf_symmetry(az_engine *e, int on);
+
 /* Opt-in: fp32-emulating conv trunk.  AZ_TRUNK_F32 (default) computes GomokuNet.forward (net.py:55-72) on the float32
  * matrix instruction in the build's canonical fp order: bit-identical to the oracle.  AZ_TRUNK_BF16X3 runs conv2 and conv3
  * (99 % of the net's arithmetic) on the 16 x faster bf16 matrix instruction with every operand split into three bf16 parts

@@ -454,6 +454,10 @@ typedef struct {
     int vl;                     /* opt-in virtual-loss batching (include/az_engine.h, az_set_virtual_loss): leaves selected per
                                    evaluation batch; 0 = the reference's sequential loop (mcts.py:123-141).  vl = 1 runs the
                                    batched code with batches of one, which must reproduce the reference exactly. */
+    int leaf_sym;               /* opt-in random-symmetry leaf evaluation (include/az_engine.h, az_set_leaf_symmetry; SURVEY 8f-2's
+                                   optional half, README.md:61,82): every evaluation shows the net one of the 8 dihedral symmetries
+                                   of the position, chosen by a fixed hash of (game_id, ply, evaluation index); 0 = the reference */
+    int game_id;                /* ... the game's id in its episode (arena: the game index; single searches: 0) */
 } orc_cfg;
 
 typedef struct {
@@ -473,12 +477,49 @@ typedef struct {
     long dup_sims;              /* virtual-loss mode: simulations that landed on a leaf already pending in their batch */
 } orc_tree;
 
-static void evaluate(const orc_cfg *cfg, const orc_net *net, const orc_state *s, float *P, float *v)
+/* dihedral symmetries: k < 4 = np.rot90 k times (counter-clockwise), k >= 4 = rot90(fliplr(x), k - 4) (games.py:183-197);
+ * source cell of output cell (i, j): sym(x)[i][j] = x[orc_sym_src(k, i, j)] */
+static int orc_sym_src(int k, int i, int j, int n)
+{
+    int si, sj;
+    switch (k & 3) {
+    case 0: si = i; sj = j; break;
+    case 1: si = j; sj = n - 1 - i; break;
+    case 2: si = n - 1 - i; sj = n - 1 - j; break;
+    default: si = n - 1 - j; sj = i; break;
+    }
+    if (k >= 4) sj = n - 1 - sj;
+    return si * n + sj;
+}
+/* the symmetry evaluation idx (0 = the root, s + 1 = simulation s) of the search of game `game` at ply `ply` shows the net */
+static int orc_leaf_sym(int game, int ply, int idx)
+{
+    return (int)(fmix32((uint32_t)game * 0x9E3779B1u ^ fmix32((uint32_t)ply * 0x85EBCA6Bu + (uint32_t)idx + 1u)) & 7u);
+}
+
+/* The net's raw outputs for a position shown under symmetry t: planes are in board order; the net sees sym_t(planes); the
+ * logits come back in BOARD order (logit of board cell j = the net's logit at the image cell j moved to). */
+void orc_net_eval_sym(const orc_net *N, int n, const float *planes, int t, float *logits_board, float *value)
+{
+    const int nn = n * n, ti = t < 4 ? ((4 - t) & 3) : t;
+    float img[4 * ORC_MAXNN], limg[ORC_MAXNN];
+    for (int ch = 0; ch < 4; ch++)
+        for (int c = 0; c < nn; c++) img[ch * nn + c] = planes[ch * nn + orc_sym_src(t, c / n, c % n, n)];
+    net_forward(N, img, limg, value);
+    for (int j = 0; j < nn; j++) logits_board[j] = limg[orc_sym_src(ti, j / n, j % n, n)];
+}
+int orc_leaf_sym_of(int game, int ply, int idx) { return orc_leaf_sym(game, ply, idx); }
+
+/* idx < 0: no symmetry (virtual-loss mode, which the option cannot be combined with) */
+static void evaluate(const orc_cfg *cfg, const orc_net *net, const orc_state *s, float *P, float *v, int ply, int idx)
 {
     if (cfg->eval_kind == 1) { synth_eval(s, P, v); return; }
     float planes[4 * ORC_MAXNN], logits[ORC_MAXNN];
     st_encode(s, planes);
-    net_forward(net, planes, logits, v);
+    if (cfg->leaf_sym && idx >= 0)      /* the usual canonical softmax runs on the logits brought back to board order */
+        orc_net_eval_sym(net, s->n, planes, orc_leaf_sym(cfg->game_id, ply, idx), logits, v);
+    else
+        net_forward(net, planes, logits, v);
     softmax_canon(s->n * s->n, logits, P);
 }
 
@@ -567,6 +608,8 @@ static int mcts_run(const orc_cfg *cfg, const orc_net *net, const orc_state *roo
     int n = cfg->n, nn = n * n;
     float P[ORC_MAXNN], v;
     int first_sim = 0;
+    int ply = 0;                                      /* stones on the board = plies played (leaf-symmetry hash) */
+    for (int a = 0; a < nn; a++) ply += root_state->cell[a] != 0;
     orc_node *root = &t->nodes[0];
     if (t->retained) {
         /* subtree reuse (not in the reference): the root kept from the previous ply is not evaluated again; its
@@ -591,7 +634,7 @@ static int mcts_run(const orc_cfg *cfg, const orc_net *net, const orc_state *roo
     t->used = 1;
     root->parent = -1; root->action = -1; root->prior = 1.0; root->N = 0; root->W = 0.0; root->first = -1; root->cnt = 0; root->vl = 0;
 
-    evaluate(cfg, net, root_state, P, &v);            /* mcts.py:109 (root value discarded) */
+    evaluate(cfg, net, root_state, P, &v, ply, 0);    /* mcts.py:109 (root value discarded) */
     if (noise) {                                      /* mcts.py:113-116, arithmetic per SURVEY Q8 */
         float om = (float)(1.0 - cfg->w);
         int i = 0;
@@ -655,7 +698,7 @@ static int mcts_run(const orc_cfg *cfg, const orc_net *net, const orc_state *roo
                 for (int nd = node; nd >= 0; nd = t->nodes[nd].parent) t->nodes[nd].vl += 1;
             }
             for (int j = 0; j < nb; j++)
-                if (kind[j] == 0) evaluate(cfg, net, &sb[j], Pb[j], &vals[j]);
+                if (kind[j] == 0) evaluate(cfg, net, &sb[j], Pb[j], &vals[j], ply, -1);
             for (int j = 0; j < nb; j++) {
                 const int node = leaf[j];
                 for (int nd = node; nd >= 0; nd = t->nodes[nd].parent) t->nodes[nd].vl -= 1;
@@ -700,7 +743,7 @@ static int mcts_run(const orc_cfg *cfg, const orc_net *net, const orc_state *roo
             value = s.winner == RES_DRAW ? 0.0 : (s.winner == s.player ? 1.0 : -1.0);
             t->terminal_hits++;
         } else {                                      /* mcts.py:136-138 */
-            evaluate(cfg, net, &s, P, &v);
+            evaluate(cfg, net, &s, P, &v, ply, sim + 1);
             expand(t, node, &s, P);
             value = (double)v;
             t->expansions++;

@@ -33,7 +33,8 @@ def build(force=False):
 class _Cfg(C.Structure):
     _fields_ = [("n", C.c_int), ("k", C.c_int), ("S", C.c_int),
                 ("c_puct", C.c_double), ("alpha", C.c_double), ("w", C.c_double),
-                ("eval_kind", C.c_int), ("log_table", C.POINTER(C.c_float)), ("reuse", C.c_int), ("vl", C.c_int)]
+                ("eval_kind", C.c_int), ("log_table", C.POINTER(C.c_float)), ("reuse", C.c_int), ("vl", C.c_int),
+                ("leaf_sym", C.c_int), ("game_id", C.c_int)]
 
 
 def lib():
@@ -47,6 +48,8 @@ def lib():
         L.orc_resnet_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.orc_net_free.argtypes = [C.c_void_p]
         L.orc_net_eval.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.orc_net_eval_sym.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_leaf_sym_of.restype = C.c_int; L.orc_leaf_sym_of.argtypes = [C.c_int, C.c_int, C.c_int]
         L.orc_search.restype = C.c_int
         L.orc_selfplay_game.restype = C.c_int
         L.orc_arena_game.restype = C.c_int
@@ -108,6 +111,14 @@ class Net:
         lib().orc_net_eval(self.h, _p(planes), _p(logits), _p(P), _p(v))
         return logits, P, float(v[0])
 
+    def eval_sym(self, planes, t):
+        """raw outputs for the position shown to the net under dihedral symmetry t (0..7); logits in board order"""
+        nn = self.n * self.n
+        planes = np.ascontiguousarray(planes, dtype=np.float32)
+        logits = np.zeros(nn, np.float32); v = np.zeros(1, np.float32)
+        lib().orc_net_eval_sym(self.h, int(self.n), _p(planes), int(t), _p(logits), _p(v))
+        return logits, float(v[0])
+
     def __del__(self):
         try:
             lib().orc_net_free(self.h)
@@ -116,11 +127,21 @@ class Net:
 
 
 class Oracle:
-    def __init__(self, n, k, S, c_puct=2.0, alpha=0.3, w=0.25, synthetic=False, log_table=None, reuse=False, virtual_loss=0):
+    def __init__(self, n, k, S, c_puct=2.0, alpha=0.3, w=0.25, synthetic=False, log_table=None, reuse=False, virtual_loss=0,
+                 leaf_sym=False):
         self.n, self.k, self.S = n, k, S
         self.log_table = numpy_log_table(max(S, 1)) if log_table is None else np.ascontiguousarray(log_table, np.float32)
         self.cfg = _Cfg(n, k, S, c_puct, alpha, w, 1 if synthetic else 0,
-                        self.log_table.ctypes.data_as(C.POINTER(C.c_float)), 1 if reuse else 0, int(virtual_loss))
+                        self.log_table.ctypes.data_as(C.POINTER(C.c_float)), 1 if reuse else 0, int(virtual_loss),
+                        1 if leaf_sym else 0, 0)
+
+    def _cfg_for(self, game):
+        """the configuration with the game id the leaf-symmetry hash uses (a copy: one Oracle serves many threads)"""
+        if not self.cfg.leaf_sym:
+            return self.cfg
+        c = _Cfg.from_buffer_copy(self.cfg)
+        c.game_id = int(game)
+        return c
 
     # ---- rules ----
     def replay(self, actions):
@@ -144,17 +165,17 @@ class Oracle:
         return P, float(v[0])
 
     # ---- search ----
-    def search(self, net, board, player, last, T, noise, u):
+    def search(self, net, board, player, last, T, noise, u, game=0):
         nn = self.n * self.n
         pi = np.zeros(nn, np.float32); N = np.zeros(nn, np.int32); W = np.zeros(nn, np.float64); P = np.zeros(nn, np.float32)
         nexp = C.c_int(); maxd = C.c_int()
         nz = None if noise is None else np.ascontiguousarray(noise, np.float64)
-        a = lib().orc_search(C.byref(self.cfg), C.c_void_p(net.h if net else None),
+        a = lib().orc_search(C.byref(self._cfg_for(game)), C.c_void_p(net.h if net else None),
                              _p(np.ascontiguousarray(board, np.uint8)), int(player), int(last), C.c_double(T),
                              _p(nz), C.c_double(u), _p(pi), _p(N), _p(W), _p(P), C.byref(nexp), C.byref(maxd))
         return dict(action=a, pi=pi, N=N, W=W, P=P, nexp=nexp.value, maxd=maxd.value)
 
-    def selfplay_game(self, net, noise_tape, u_tape, T_table=None, maxply=None):
+    def selfplay_game(self, net, noise_tape, u_tape, T_table=None, maxply=None, game=0):
         nn = self.n * self.n
         maxply = nn if maxply is None else maxply
         T_table = selfplay_T_table(nn) if T_table is None else np.ascontiguousarray(T_table, np.float64)
@@ -164,7 +185,7 @@ class Oracle:
         res = C.c_int(); counters = np.zeros(8, np.int64)
         nz = None if noise_tape is None else np.ascontiguousarray(noise_tape, np.float64)
         ut = np.ascontiguousarray(u_tape, np.float64)
-        m = lib().orc_selfplay_game(C.byref(self.cfg), C.c_void_p(net.h if net else None), _p(nz), _p(ut), _p(T_table),
+        m = lib().orc_selfplay_game(C.byref(self._cfg_for(game)), C.c_void_p(net.h if net else None), _p(nz), _p(ut), _p(T_table),
                                     int(maxply), _p(boards), _p(movers), _p(lasts), _p(pis), _p(visits), _p(actions),
                                     _p(z), C.byref(res), _p(counters))
         return dict(nply=m, boards=boards[:m], movers=movers[:m], lasts=lasts[:m], pis=pis[:m], visits=visits[:m],
@@ -177,7 +198,7 @@ class Oracle:
         T_table = arena_T_table(nn) if T_table is None else np.ascontiguousarray(T_table, np.float64)
         actions = np.zeros(nn, np.int16); temps = np.zeros(nn, np.float64); nply = C.c_int()
         ut = np.ascontiguousarray(u_tape, np.float64)
-        r = lib().orc_arena_game(C.byref(self.cfg), C.c_void_p(cand.h), C.c_void_p(base.h), int(game_index), _p(ut),
+        r = lib().orc_arena_game(C.byref(self._cfg_for(game_index)), C.c_void_p(cand.h), C.c_void_p(base.h), int(game_index), _p(ut),
                                  _p(T_table), _p(actions), _p(temps), C.byref(nply))
         return dict(result=r, nply=nply.value, actions=actions[:nply.value], temps=temps[:nply.value])
 

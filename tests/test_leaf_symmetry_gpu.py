@@ -1,0 +1,107 @@
+"""GPU tests of opt-in random-symmetry leaf evaluation (az_set_leaf_symmetry): the engine against the oracle's restatement
+(orc_cfg.leaf_sym), bit for bit -- the symmetry of every evaluation is a fixed hash of (game, ply, evaluation index), the
+forward pass is the canonical-order one, so nothing is left to tolerance.  "Parity unpinned" by the reference, which has no
+such mode (tests/test_leaf_symmetry_cpu.py pins the oracle's symmetries to numpy's rot90 / fliplr)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc
+from tests.util import build_weights, weights_from_fixture
+
+import alphazero_piskvorky_amd as az
+from alphazero_piskvorky_amd import _capi
+
+
+def _nets(n, model):
+    if model == "resnet":
+        from alphazero_piskvorky_amd.net import fold_resnet_state_dict
+        from alphazero_piskvorky_amd.weights import synthetic_resnet_state_dict
+        sd = synthetic_resnet_state_dict(n)
+        return sd, orc.Net(n, resnet_tensors=fold_resnet_state_dict(sd))
+    sd = build_weights(n)
+    return sd, orc.Net(n, sd)
+
+
+@pytest.mark.parametrize("split", ["0", "1000000"])
+@pytest.mark.parametrize("n,k,S,G,cut,model", [(5, 4, 40, 6, 0, "plain"), (9, 5, 30, 4, 6, "plain"), (15, 5, 16, 3, 4, "plain"),
+                                               (9, 5, 24, 3, 5, "resnet")])
+def test_selfplay_with_leaf_symmetry_bit_exact_vs_oracle(n, k, S, G, cut, model, split, monkeypatch):
+    monkeypatch.setenv("AZ_SPLIT_MAX", split)
+    seed0 = 7700
+    sd, onet = _nets(n, model)
+    e = az.Engine(n, k, S, 3, log_table=orc.numpy_log_table(S), model=model)       # fewer slots than games: refills included
+    e.load_weights(sd, 0)
+    e.set_leaf_symmetry(True)
+    c = e.selfplay(G, seed0=seed0, max_plies=cut)
+    assert e.persistent() == 0            # the option runs on the lock-step pipeline
+    rec = e.records(); nply, res = e.games()
+    o = orc.Oracle(n, k, S, leaf_sym=True)
+    plain = orc.Oracle(n, k, S)
+    off, differs = 0, 0
+    for g in range(G):
+        noise, us = orc.selfplay_tape(seed0 + g, n, maxply=cut or None)
+        r = o.selfplay_game(onet, noise, us, maxply=cut or None, game=g)
+        L = int(nply[g]); sl = slice(off, off + L)
+        assert L == r["nply"], f"game {g}"
+        for key in ("actions", "boards", "visits", "pis"):
+            assert np.array_equal(rec[key][sl], r[key]), f"game {g}: {key} differs from the oracle"
+        if not cut:
+            assert int(res[g]) == r["result"] and np.array_equal(rec["z"][sl], r["z"])
+        differs += not np.array_equal(plain.selfplay_game(onet, noise, us, maxply=cut or None)["visits"][:1], r["visits"][:1])
+        off += L
+    assert differs > 0, "the option changed nothing: no game's first search differs from the unrotated one"
+    assert c["simulations"] == S * c["plies"]
+    e.set_leaf_symmetry(False)            # and the default comes back bit-exact
+    e.selfplay(1, seed0=seed0, max_plies=cut)
+    r0 = plain.selfplay_game(onet, *orc.selfplay_tape(seed0, n, maxply=cut or None), maxply=cut or None)
+    assert np.array_equal(e.records()["visits"], r0["visits"])
+    e.close()
+
+
+def test_single_search_and_arena_with_leaf_symmetry():
+    n, k, S = 5, 4, 50
+    cand, base = weights_from_fixture(n, "ckpt_saved"), weights_from_fixture(n, "ckpt_0802")
+    e = az.Engine(n, k, S, 4, log_table=orc.numpy_log_table(S))
+    e.load_weights(cand, 0); e.load_weights(base, 1)
+    e.set_leaf_symmetry(True)
+    o = orc.Oracle(n, k, S, leaf_sym=True)
+    oc, ob = orc.Net(n, cand), orc.Net(n, base)
+    board = np.zeros(n * n, np.uint8); board[[12, 7, 8]] = [1, 2, 1]
+    noise = np.random.RandomState(4).dirichlet([0.3] * (n * n - 3))
+    r = e.search(board, 2, 8, 0.9, noise, 0.61)
+    ro = o.search(oc, board, 2, 8, 0.9, noise, 0.61, game=0)
+    assert np.array_equal(r["N"], ro["N"]) and np.array_equal(r["P"], ro["P"]) and np.array_equal(r["W"], ro["W"])
+    assert np.array_equal(r["pi"], ro["pi"]) and r["action"] == ro["action"]
+    G = 6
+    a = e.arena(G, seed0=31, temperature_table=orc.arena_T_table(n * n))
+    for g in range(G):
+        us = np.random.RandomState(31 + g).random_sample(n * n)
+        rg = o.arena_game(oc, ob, g, us)
+        assert int(a["nply"][g]) == rg["nply"] and int(a["results"][g]) == rg["result"]
+        assert np.array_equal(a["actions"][g][:rg["nply"]], rg["actions"])
+    e.close()
+
+
+def test_leaf_symmetry_with_the_emulated_trunk_and_rejected_combinations():
+    n, k, S = 9, 5, 40
+    e = az.Engine(n, k, S, 4)
+    e.load_weights(build_weights(n), 0)
+    e.set_leaf_symmetry(True)
+    e.set_trunk_mode("bf16x3")            # both opt-ins together: runs, every search makes its S simulations
+    c = e.selfplay(4, seed0=3, max_plies=5)
+    assert c["simulations"] == S * c["plies"] and int(e.records()["visits"].sum()) == S * c["plies"]
+    e.set_trunk_mode("f32")
+    for call in (lambda: e.set_virtual_loss(4), lambda: e.set_subtree_reuse(True), lambda: e.set_eval_cache(1024)):
+        with pytest.raises(_capi.AzError):
+            call()
+    e.set_leaf_symmetry(False)
+    e.set_virtual_loss(4)
+    with pytest.raises(_capi.AzError):
+        e.set_leaf_symmetry(True)
+    e.close()
+    s = az.Engine(5, 4, 8, 2, synthetic=True)
+    with pytest.raises(_capi.AzError):
+        s.set_leaf_symmetry(True)         # the synthetic evaluator is not a net
+    s.close()
