@@ -23,7 +23,7 @@ AZ_EVAL_NET, AZ_EVAL_SYNTHETIC = 0, 1
 AZ_RES_NONE, AZ_RES_X, AZ_RES_O, AZ_RES_DRAW = 0, 1, 2, 3
 AZ_AUG_NONE, AZ_AUG_REFERENCE4, AZ_AUG_DIHEDRAL8 = 1, 4, 8
 AZ_MODEL_PLAIN, AZ_MODEL_RESNET = 0, 1
-AZ_TRUNK_F32, AZ_TRUNK_BF16X3 = 0, 1
+AZ_TRUNK_F32, AZ_TRUNK_BF16X3, AZ_TRUNK_F16X2 = 0, 1, 2
 
 EXPORTS = [
     "az_create", "az_destroy", "az_last_error", "az_load_weights", "az_load_weights_resnet", "az_net_eval", "az_search", "az_search_callback", "az_selfplay",
@@ -379,13 +379,14 @@ class Engine:
         self._check(lib().az_set_leaf_symmetry(self.h, 1 if on else 0), "az_set_leaf_symmetry")
 
     def set_trunk_mode(self, mode):
-        """Opt-in: "bf16x3" = fp32-emulating conv trunk on the bf16 matrix cores (tolerance instead of bit-exactness),
-        "f32" = the default canonical float32 trunk.  See include/az_engine.h."""
-        code = {"f32": AZ_TRUNK_F32, "bf16x3": AZ_TRUNK_BF16X3}.get(mode, mode)
+        """Opt-in: "bf16x3" / "f16x2" = fp32-emulating conv trunks on the 16-bit matrix cores (tolerance instead of
+        bit-exactness; f16x2 is the faster one and has float16's range), "f32" = the default canonical float32 trunk.
+        See include/az_engine.h."""
+        code = {"f32": AZ_TRUNK_F32, "bf16x3": AZ_TRUNK_BF16X3, "f16x2": AZ_TRUNK_F16X2}.get(mode, mode)
         self._check(lib().az_set_trunk_mode(self.h, int(code)), "az_set_trunk_mode")
 
     def trunk_mode(self):
-        return "bf16x3" if int(lib().az_get_trunk_mode(self.h)) == AZ_TRUNK_BF16X3 else "f32"
+        return {AZ_TRUNK_BF16X3: "bf16x3", AZ_TRUNK_F16X2: "f16x2"}.get(int(lib().az_get_trunk_mode(self.h)), "f32")
 
     def set_profiling(self, on):
         lib().az_set_profiling(self.h, 1 if on else 0)

@@ -33,8 +33,9 @@ struct PackedNet {
     bool loaded = false;
     DevBuf c1, c2, c3, hd, pf, vf, c1b, c2b, c3b, hdb, pfb, vfb, v2w, v2b;
     DevBuf rblk[6], rblkb[6];          // ResidualBlock variant: the six 64->64 convs (c1/c1b hold the stem)
-    DevBuf c2x, c3x, hdx;              // conv2 / conv3 / head convs split three ways into bf16 MFMA fragments (az_net_bf3.h)
-    DevBuf rblkx[6];                   // ... and the six 64 -> 64 convs of the ResidualBlock variant
+    DevBuf c2x[2], c3x[2], hdx[2];     // conv2 / conv3 / head convs split into 16-bit MFMA fragments (az_net_emul.h): [0] bf16x3, [1] f16x2
+    DevBuf rblkx[2][6];                // ... and the six 64 -> 64 convs of the ResidualBlock variant
+    bool f16_ok = true;                // every weight of the emulated layers is inside float16's range (AZ_TRUNK_F16X2)
     NetWeights w{};
     ResWeights rw{};
 };
@@ -84,7 +85,7 @@ struct az_engine {
     bool vl_kernel = false;        // the batched tree kernel is in use (vl > 1, or AZ_VL_FORCE=1 to run it with batches of one)
     bool persist_allowed = true;   // AZ_PERSIST=0: never use the persistent search kernel
     int leaf_symmetry = 0;         // az_set_leaf_symmetry: every evaluation shows the net a pseudo-random dihedral symmetry of the position
-    int trunk_mode = AZ_TRUNK_F32; // az_set_trunk_mode: AZ_TRUNK_BF16X3 = conv2 / conv3 on the bf16 MFMA, three-way split operands
+    int trunk_mode = AZ_TRUNK_F32; // az_set_trunk_mode: AZ_TRUNK_BF16X3 / AZ_TRUNK_F16X2 = the convs on the 16-bit MFMAs with split operands
     int persist_gp = 0;            // games per workgroup of the persistent search kernel for the open episode, 0 = lock-step pipeline
     DevBuf cache;                  // evaluation cache shared by the lanes (az_set_eval_cache)
     unsigned cache_mask = 0, cache_gen = 1;
@@ -122,7 +123,7 @@ static LaunchCtx ctx_of_impl(const az_engine *e, const Lane &L)
     c.synthetic = e->cfg.eval_kind == AZ_EVAL_SYNTHETIC;
     c.persist_gp = e->persist_gp;
     c.vl_kernel = e->vl_kernel ? 1 : 0;
-    c.emul = e->trunk_mode == AZ_TRUNK_BF16X3 ? 1 : 0;
+    c.emul = e->trunk_mode;        // AZ_TRUNK_F32 = 0, AZ_TRUNK_BF16X3 = EMUL_BF16X3, AZ_TRUNK_F16X2 = EMUL_F16X2
     c.feat = (float *)L.pol_feat.p;
     c.dbg = (unsigned long long *)L.dbg.p;
     c.scratch = (float *)L.scratch.p;
@@ -226,10 +227,12 @@ static std::vector<float> pack_conv(const float *w, int cout, int cin)
             }
     return out;
 }
-// fp32-emulating trunk (az_net_bf3.h): A-operand fragments of v_mfma_f32_16x16x32_bf16 with every weight split three
-// ways, w = hi + mid + lo (each the round-to-nearest-even bf16 of what the previous parts left over).  Lane l supplies
-// A[row = l & 15][k = 8 (l >> 4) + j]; K-block kb = one tap x 32 input channels:
-//   packed[(((ntile * KB + kb) * 3 + split) * 64 + lane) * 8 + j]
+// fp32-emulating trunks (az_net_emul.h): A-operand fragments of the 16-bit MFMAs with every weight split into parts.
+//   scheme 1 (AZ_TRUNK_BF16X3): w = hi + mid + lo, three bfloat16 parts, each the round-to-nearest-even bf16 of what the
+//                               previous parts left over;
+//   scheme 2 (AZ_TRUNK_F16X2):  w = hi + lo / 2048, two float16 parts, lo stored scaled by 2^11.
+// Conv layers: lane l supplies A[row = l & 15][k = 8 (l >> 4) + j]; K-block kb = one tap x 32 input channels:
+//   packed[(((ntile * KB + kb) * NS + part) * 64 + lane) * 8 + j]
 static inline uint16_t bf16_rne(float x)
 {
     uint32_t u;
@@ -244,43 +247,67 @@ static inline float bf16_val(uint16_t h)
     memcpy(&f, &u, 4);
     return f;
 }
-static std::vector<uint16_t> pack_conv_bf3(const float *w, int cout, int cin)
+static inline uint16_t f16_rne(float x)
 {
-    const int kbt = cin / 32, kb_n = 9 * kbt, nt = cout / 16;
-    std::vector<uint16_t> out((size_t)nt * kb_n * 3 * 64 * 8, 0);
+    const _Float16 h = (_Float16)x;             // round to nearest even
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+static inline float f16_val(uint16_t u)
+{
+    _Float16 h;
+    memcpy(&h, &u, 2);
+    return (float)h;
+}
+static inline int emul_parts(int scheme) { return scheme == AZ_TRUNK_F16X2 ? 2 : 3; }
+// the parts of one weight; false when the value is outside the scheme's range
+static inline bool emul_split(int scheme, float x, uint16_t *parts)
+{
+    if (scheme == AZ_TRUNK_F16X2) {
+        if (!(std::fabs(x) < 65504.0f)) { parts[0] = parts[1] = 0; return false; }
+        parts[0] = f16_rne(x);
+        parts[1] = f16_rne((x - f16_val(parts[0])) * 2048.0f);
+        return true;
+    }
+    parts[0] = bf16_rne(x);
+    const float r1 = x - bf16_val(parts[0]);
+    parts[1] = bf16_rne(r1);
+    parts[2] = bf16_rne(r1 - bf16_val(parts[1]));
+    return true;
+}
+static std::vector<uint16_t> pack_conv_emul(int scheme, const float *w, int cout, int cin, bool *ok)
+{
+    const int ns = emul_parts(scheme), kbt = cin / 32, kb_n = 9 * kbt, nt = cout / 16;
+    std::vector<uint16_t> out((size_t)nt * kb_n * ns * 64 * 8, 0);
     for (int t = 0; t < nt; t++)
         for (int kb = 0; kb < kb_n; kb++)
             for (int lane = 0; lane < 64; lane++)
                 for (int j = 0; j < 8; j++) {
                     const int tap = kb / kbt, ci = (kb % kbt) * 32 + 8 * (lane >> 4) + j, co = t * 16 + (lane & 15);
-                    const float x = w[((size_t)co * cin + ci) * 9 + tap];
-                    const uint16_t hi = bf16_rne(x);
-                    const float r1 = x - bf16_val(hi);
-                    const uint16_t mid = bf16_rne(r1);
-                    const uint16_t lo = bf16_rne(r1 - bf16_val(mid));
-                    const size_t base = (((size_t)t * kb_n + kb) * 3 * 64 + lane) * 8 + j;
-                    out[base] = hi; out[base + 64 * 8] = mid; out[base + 2 * 64 * 8] = lo;
+                    uint16_t parts[3];
+                    if (!emul_split(scheme, w[((size_t)co * cin + ci) * 9 + tap], parts)) *ok = false;
+                    const size_t base = (((size_t)t * kb_n + kb) * ns * 64 + lane) * 8 + j;
+                    for (int s2 = 0; s2 < ns; s2++) out[base + (size_t)s2 * 64 * 8] = parts[s2];
                 }
     return out;
 }
-// The 1x1 head convs for the fused epilogue of the emulated conv3: A-operand fragments of v_mfma_f32_16x16x16_bf16, one per
-// 16-channel tile of the conv3 output; lane l supplies A[row = l & 15 = head channel][k = 4 (l >> 4) + j] = w[row][16 tile + k]:
-//   packed[((tile * 3 + split) * 64 + lane) * 4 + j]
-static std::vector<uint16_t> pack_heads_bf3(const float *pw, int pc, const float *vw, int vc, int cin)
+// The 1x1 head convs for the fused epilogue of the last emulated conv: A-operand fragments of the 16x16x16 MFMA, one per
+// 16-channel tile of that conv's output; lane l supplies A[row = l & 15 = head channel][k = 4 (l >> 4) + j] = w[row][16 tile + k]:
+//   packed[((tile * NS + part) * 64 + lane) * 4 + j]
+static std::vector<uint16_t> pack_heads_emul(int scheme, const float *pw, int pc, const float *vw, int vc, int cin, bool *ok)
 {
-    const int nt = cin / 16;
-    std::vector<uint16_t> out((size_t)nt * 3 * 64 * 4, 0);
+    const int ns = emul_parts(scheme), nt = cin / 16;
+    std::vector<uint16_t> out((size_t)nt * ns * 64 * 4, 0);
     for (int t = 0; t < nt; t++)
         for (int lane = 0; lane < 64; lane++)
             for (int j = 0; j < 4; j++) {
                 const int row = lane & 15, ci = 16 * t + 4 * (lane >> 4) + j;
                 const float x = row < pc ? pw[row * cin + ci] : (row < pc + vc ? vw[(row - pc) * cin + ci] : 0.0f);
-                const uint16_t hi = bf16_rne(x);
-                const float r1 = x - bf16_val(hi);
-                const uint16_t mid = bf16_rne(r1);
-                const uint16_t lo = bf16_rne(r1 - bf16_val(mid));
-                const size_t base = ((size_t)t * 3 * 64 + lane) * 4 + j;
-                out[base] = hi; out[base + 64 * 4] = mid; out[base + 2 * 64 * 4] = lo;
+                uint16_t parts[3];
+                if (!emul_split(scheme, x, parts)) *ok = false;
+                const size_t base = ((size_t)t * ns * 64 + lane) * 4 + j;
+                for (int s2 = 0; s2 < ns; s2++) out[base + (size_t)s2 * 64 * 4] = parts[s2];
             }
     return out;
 }
@@ -632,9 +659,9 @@ extern "C" void az_destroy(az_engine *e)
     for (DevBuf *b : shared) dev_free(*b);
     for (int s = 0; s < 2; s++) {
         PackedNet &p = e->net[s];
-        DevBuf *nb[] = {&p.c1, &p.c2, &p.c3, &p.hd, &p.pf, &p.vf, &p.c1b, &p.c2b, &p.c3b, &p.hdb, &p.pfb, &p.vfb, &p.v2w, &p.v2b, &p.c2x, &p.c3x, &p.hdx};
+        DevBuf *nb[] = {&p.c1, &p.c2, &p.c3, &p.hd, &p.pf, &p.vf, &p.c1b, &p.c2b, &p.c3b, &p.hdb, &p.pfb, &p.vfb, &p.v2w, &p.v2b, &p.c2x[0], &p.c2x[1], &p.c3x[0], &p.c3x[1], &p.hdx[0], &p.hdx[1]};
         for (DevBuf *b : nb) dev_free(*b);
-        for (int i = 0; i < 6; i++) { dev_free(p.rblk[i]); dev_free(p.rblkb[i]); dev_free(p.rblkx[i]); }
+        for (int i = 0; i < 6; i++) { dev_free(p.rblk[i]); dev_free(p.rblkb[i]); dev_free(p.rblkx[0][i]); dev_free(p.rblkx[1][i]); }
     }
     for (Lane &L : e->lanes)
         if (L.stream) g_streams.release(e->cfg.device, true, L.stream);
@@ -656,12 +683,15 @@ extern "C" int az_load_weights(az_engine *e, int slot, const float *const *t)
     up(p.c1, pack_conv(t[0], 32, 4));   upraw(p.c1b, t[1], 32);
     up(p.c2, pack_conv(t[2], 64, 32));  upraw(p.c2b, t[3], 64);
     up(p.c3, pack_conv(t[4], 128, 64)); upraw(p.c3b, t[5], 128);
-    {
-        const std::vector<uint16_t> x2 = pack_conv_bf3(t[2], 64, 32), x3 = pack_conv_bf3(t[4], 128, 64);
-        if (!rc) rc = upload(e, p.c2x, x2.data(), x2.size() * 2);
-        if (!rc) rc = upload(e, p.c3x, x3.data(), x3.size() * 2);
-        const std::vector<uint16_t> xh = pack_heads_bf3(t[6], 4, t[10], 2, 128);
-        if (!rc) rc = upload(e, p.hdx, xh.data(), xh.size() * 2);
+    p.f16_ok = true;
+    for (int sch = AZ_TRUNK_BF16X3; sch <= AZ_TRUNK_F16X2 && !rc; sch++) {
+        bool ok = true;
+        const std::vector<uint16_t> x2 = pack_conv_emul(sch, t[2], 64, 32, &ok), x3 = pack_conv_emul(sch, t[4], 128, 64, &ok);
+        const std::vector<uint16_t> xh = pack_heads_emul(sch, t[6], 4, t[10], 2, 128, &ok);
+        if (!rc) rc = upload(e, p.c2x[sch - 1], x2.data(), x2.size() * 2);
+        if (!rc) rc = upload(e, p.c3x[sch - 1], x3.data(), x3.size() * 2);
+        if (!rc) rc = upload(e, p.hdx[sch - 1], xh.data(), xh.size() * 2);
+        if (sch == AZ_TRUNK_F16X2) p.f16_ok = ok;
     }
     up(p.hd, pack_heads(t[6], 4, t[10], 2, 128));
     float hb[6] = {t[7][0], t[7][1], t[7][2], t[7][3], t[11][0], t[11][1]};
@@ -674,10 +704,14 @@ extern "C" int az_load_weights(az_engine *e, int slot, const float *const *t)
     p.w.hd = (const float *)p.hd.p; p.w.pf = (const float *)p.pf.p; p.w.vf = (const float *)p.vf.p;
     p.w.c1b = (const float *)p.c1b.p; p.w.c2b = (const float *)p.c2b.p; p.w.c3b = (const float *)p.c3b.p;
     p.w.hdb = (const float *)p.hdb.p; p.w.pfb = (const float *)p.pfb.p; p.w.vfb = (const float *)p.vfb.p;
-    p.w.c2x = p.c2x.p; p.w.c3x = p.c3x.p; p.w.hdx = p.hdx.p;
+    for (int i = 0; i < 2; i++) { p.w.c2x[i] = p.c2x[i].p; p.w.c3x[i] = p.c3x[i].p; p.w.hdx[i] = p.hdx[i].p; }
     e->cache_gen++;           // evaluations cached under the previous weights never match again
     each_state(e, [&](DevState &d) { d.v2w[slot] = (const float *)p.v2w.p; d.v2b[slot] = (const float *)p.v2b.p; d.cache_gen = e->cache_gen; });
     p.loaded = true;
+    if (e->trunk_mode == AZ_TRUNK_F16X2 && !p.f16_ok) {
+        e->trunk_mode = AZ_TRUNK_F32;       // never run a net outside float16's range in the float16 scheme
+        return fail(e, AZ_ERR_INVALID, "weights outside float16's range (|w| >= 65504): AZ_TRUNK_F16X2 switched off, the engine is back on AZ_TRUNK_F32");
+    }
     return AZ_OK;
 }
 
@@ -695,13 +729,16 @@ extern "C" int az_load_weights_resnet(az_engine *e, int slot, const float *const
     auto upraw = [&](DevBuf &b, const float *v, size_t cnt) { if (!rc) rc = upload(e, b, v, cnt * sizeof(float)); };
     up(p.c1, pack_conv(t[0], 64, 4)); upraw(p.c1b, t[1], 64);
     for (int i = 0; i < 6; i++) { up(p.rblk[i], pack_conv(t[2 + 2 * i], 64, 64)); upraw(p.rblkb[i], t[3 + 2 * i], 64); }
-    for (int i = 0; i < 6; i++) {
-        const std::vector<uint16_t> x = pack_conv_bf3(t[2 + 2 * i], 64, 64);
-        if (!rc) rc = upload(e, p.rblkx[i], x.data(), x.size() * 2);
-    }
-    {
-        const std::vector<uint16_t> xh = pack_heads_bf3(t[14], 2, t[16], 1, 64);
-        if (!rc) rc = upload(e, p.hdx, xh.data(), xh.size() * 2);
+    p.f16_ok = true;
+    for (int sch = AZ_TRUNK_BF16X3; sch <= AZ_TRUNK_F16X2 && !rc; sch++) {
+        bool ok = true;
+        for (int i = 0; i < 6 && !rc; i++) {
+            const std::vector<uint16_t> x = pack_conv_emul(sch, t[2 + 2 * i], 64, 64, &ok);
+            rc = upload(e, p.rblkx[sch - 1][i], x.data(), x.size() * 2);
+        }
+        const std::vector<uint16_t> xh = pack_heads_emul(sch, t[14], 2, t[16], 1, 64, &ok);
+        if (!rc) rc = upload(e, p.hdx[sch - 1], xh.data(), xh.size() * 2);
+        if (sch == AZ_TRUNK_F16X2) p.f16_ok = ok;
     }
     up(p.hd, pack_heads(t[14], 2, t[16], 1, 64));
     float hb[3] = {t[15][0], t[15][1], t[17][0]};
@@ -713,14 +750,20 @@ extern "C" int az_load_weights_resnet(az_engine *e, int slot, const float *const
     p.rw.stem = (const float *)p.c1.p; p.rw.stemb = (const float *)p.c1b.p;
     for (int i = 0; i < 6; i++) { p.rw.blk[i] = (const float *)p.rblk[i].p; p.rw.blkb[i] = (const float *)p.rblkb[i].p; }
     p.rw.hd = (const float *)p.hd.p; p.rw.hdb = (const float *)p.hdb.p;
-    for (int i = 0; i < 6; i++) p.rw.blkx[i] = p.rblkx[i].p;
-    p.rw.hdx = p.hdx.p;
+    for (int sch = 0; sch < 2; sch++) {
+        for (int i = 0; i < 6; i++) p.rw.blkx[sch][i] = p.rblkx[sch][i].p;
+        p.rw.hdx[sch] = p.hdx[sch].p;
+    }
     p.w = NetWeights{};
     p.w.pf = (const float *)p.pf.p; p.w.vf = (const float *)p.vf.p;
     p.w.pfb = (const float *)p.pfb.p; p.w.vfb = (const float *)p.vfb.p;
     e->cache_gen++;           // evaluations cached under the previous weights never match again
     each_state(e, [&](DevState &d) { d.v2w[slot] = (const float *)p.v2w.p; d.v2b[slot] = (const float *)p.v2b.p; d.cache_gen = e->cache_gen; });
     p.loaded = true;
+    if (e->trunk_mode == AZ_TRUNK_F16X2 && !p.f16_ok) {
+        e->trunk_mode = AZ_TRUNK_F32;       // never run a net outside float16's range in the float16 scheme
+        return fail(e, AZ_ERR_INVALID, "weights outside float16's range (|w| >= 65504): AZ_TRUNK_F16X2 switched off, the engine is back on AZ_TRUNK_F32");
+    }
     return AZ_OK;
 }
 
@@ -1609,7 +1652,11 @@ extern "C" int az_set_trunk_mode(az_engine *e, int mode)
 {
     if (!e) return AZ_ERR_INVALID;
     if (e->run.open) return fail(e, AZ_ERR_STATE, "az_set_trunk_mode: an episode is open");
-    if (mode != AZ_TRUNK_F32 && mode != AZ_TRUNK_BF16X3) return fail(e, AZ_ERR_INVALID, "az_set_trunk_mode: unknown mode %d", mode);
+    if (mode != AZ_TRUNK_F32 && mode != AZ_TRUNK_BF16X3 && mode != AZ_TRUNK_F16X2) return fail(e, AZ_ERR_INVALID, "az_set_trunk_mode: unknown mode %d", mode);
+    if (mode == AZ_TRUNK_F16X2)
+        for (int i = 0; i < 2; i++)
+            if (e->net[i].loaded && !e->net[i].f16_ok)
+                return fail(e, AZ_ERR_INVALID, "az_set_trunk_mode: weight slot %d holds a value outside float16's range (|w| >= 65504): use AZ_TRUNK_BF16X3", i);
     if (mode != e->trunk_mode) {
         e->trunk_mode = mode;
         e->cache_gen++;           // cached evaluations of the other arithmetic never match again

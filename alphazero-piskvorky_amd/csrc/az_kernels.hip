@@ -16,13 +16,18 @@ void trunk(const LaunchCtx &c, int net_id)
     if (c.model == 1) {
         typedef ResGeo<N> G;
         dim3 gt((c.dv.B + G::G - 1) / G::G), bt(G::NW * 64);
-        if (c.emul) hipLaunchKernelGGL(k_trunk_res_bf3<N>, gt, dim3(ResGeoBf3<N>::NW * 64), 0, c.stream, c.dv, c.rw[net_id], net_id, c.feat);
+        if (c.emul == EMUL_BF16X3) hipLaunchKernelGGL((k_trunk_res_emul<N, EMUL_BF16X3>), gt, dim3(ResGeoEmul<N>::NW * 64), 0, c.stream, c.dv, c.rw[net_id], net_id, c.feat);
+        else if (c.emul == EMUL_F16X2) hipLaunchKernelGGL((k_trunk_res_emul<N, EMUL_F16X2>), gt, dim3(ResGeoEmul<N>::NW * 64), 0, c.stream, c.dv, c.rw[net_id], net_id, c.feat);
         else hipLaunchKernelGGL(k_trunk_res<N>, gt, bt, 0, c.stream, c.dv, c.rw[net_id], net_id, c.feat);
     } else {
         typedef NetGeo<N> G;
         const int ngroups = (c.dv.B + G::G - 1) / G::G;
-        if (c.emul) {
-            hipLaunchKernelGGL(k_trunk_bf3<N>, dim3(ngroups), dim3(G::NW * 64), 0, c.stream, c.dv, c.w[net_id], net_id, c.feat, c.dbg);
+        if (c.emul == EMUL_BF16X3) {
+            hipLaunchKernelGGL((k_trunk_emul<N, EMUL_BF16X3>), dim3(ngroups), dim3(G::NW * 64), 0, c.stream, c.dv, c.w[net_id], net_id, c.feat, c.dbg);
+            return;
+        }
+        if (c.emul == EMUL_F16X2) {
+            hipLaunchKernelGGL((k_trunk_emul<N, EMUL_F16X2>), dim3(ngroups), dim3(G::NW * 64), 0, c.stream, c.dv, c.w[net_id], net_id, c.feat, c.dbg);
             return;
         }
         dim3 gt(AZ_SEQ == 0 ? (ngroups < 256 ? ngroups : 256) : (ngroups + AZ_SEQ - 1) / AZ_SEQ), bt(G::NW * 64);

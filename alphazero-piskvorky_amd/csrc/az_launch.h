@@ -2,7 +2,7 @@
 // (az_kernels.hip compiled with -DAZ_N=n, in parallel); the engine dispatches through this table.
 #pragma once
 #include "az_net.h"
-#include "az_net_bf3.h"
+#include "az_net_emul.h"
 #include "az_search.h"
 
 struct LaunchCtx {
@@ -16,7 +16,7 @@ struct LaunchCtx {
     int synthetic;      // AZ_EVAL_SYNTHETIC
     int persist_gp;     // games per workgroup of the persistent search kernel, 0 = lock-step pipeline (part of the graph key)
     int vl_kernel;      // the batched (virtual-loss) tree kernel is in use (part of the graph key)
-    int emul;           // AZ_TRUNK_BF16X3: conv2 / conv3 on the bf16 MFMA with three-way split operands (az_net_bf3.h)
+    int emul;           // 0 | AZ_TRUNK_BF16X3 | AZ_TRUNK_F16X2: the convs on the 16-bit MFMA with split operands (az_net_emul.h)
     float *feat;
     unsigned long long *dbg;
     float *scratch;     // split-trunk images, SizeOps::split_floats_per_group floats per board group (or null)

@@ -95,8 +95,8 @@ def main():
     ap.add_argument("--subtree-reuse", action="store_true", help="opt-in search upgrade (not the reference's algorithm): keep the chosen child's subtree between plies")
     ap.add_argument("--eval-cache", type=int, default=0, help="opt-in search upgrade (results unchanged): device evaluation cache with this many entries")
     ap.add_argument("--virtual-loss", type=int, default=1, help="opt-in search upgrade (not the reference's algorithm): leaves per search and evaluation batch")
-    ap.add_argument("--trunk", default="f32", choices=["f32", "bf16x3"], help="f32 = the canonical float32 conv trunk (bit-exact against the oracle, the "
-                    "headline); bf16x3 = opt-in fp32-emulating trunk on the bf16 matrix cores (tolerance instead of bit-exactness)")
+    ap.add_argument("--trunk", default="f32", choices=["f32", "bf16x3", "f16x2"], help="f32 = the canonical float32 conv trunk (bit-exact against the oracle, the "
+                    "headline); bf16x3 / f16x2 = opt-in fp32-emulating trunks on the 16-bit matrix cores (tolerance instead of bit-exactness)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--pmc-run", action="store_true", help="counter-collection run: 8 sims per move so the pass stays short")
     a = ap.parse_args()
@@ -224,8 +224,8 @@ def main():
         launches = max(cal["trunk_launches"], 1)
         avg_ms = cal["trunk_seconds"] * 1e3 / launches
         achieved = (boards / launches) * trunk_f / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        # f32 MFMA spec peak; the emulated trunk issues 6 bf16 MFMA products per float32 product: bf16 dense peak / 6
-        peak = 157.3 if a.trunk == "f32" else 2500.0 / 6.0
+        # f32 MFMA spec peak; the emulated trunks issue 6 (bf16x3) or 3 (f16x2) 16-bit MFMA products per float32 product: dense peak / 6 or / 3
+        peak = 157.3 if a.trunk == "f32" else 2500.0 / (6.0 if a.trunk == "bf16x3" else 3.0)
         agg = (d["expansions"] + d["plies"]) * trunk_f / dt / 1e12   # trunk FLOPs of this rank per wall second, timed region
         # HBM bytes per launch from the committed PMC passes (FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as is)
         traffic, traffic_src = None, None
@@ -236,7 +236,7 @@ def main():
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))[f"k_trunk<{n}>"]
                 traffic = pm["hbm_bytes_per_board"] * boards / launches
                 traffic_src = "profiles/r01_pmc_summary.json (separate --pmc passes, per board x boards per launch)"
-            else:
+            elif a.trunk == "bf16x3":
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bf16x3_summary.json")))[f"k_trunk_bf3<{n}>"]
                 # FETCH_SIZE / WRITE_SIZE in KiB per dispatch; FETCH_SIZE doubled per the gfx950 note (16-B-per-lane streams count half)
                 per_board = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0 / (pm["grid"] / pm["workgroup"])
@@ -277,11 +277,12 @@ def main():
             "metric": "mcts_node_expansions_per_sec", "value": exp_all / dt, "unit": "node-expansions/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / max(a.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.trunk == "f32" else "bf16x3 (float32 emulated by three-way bf16 splits, float32 accumulate; NOT the bit-exact default)",
+            "dtype": "f32" if a.trunk == "f32" else ("bf16x3 (float32 emulated by three-way bf16 splits, float32 accumulate; NOT the bit-exact default)" if a.trunk == "bf16x3"
+                      else "f16x2 (float32 emulated by two-way float16 splits, float32 accumulate; NOT the bit-exact default)"),
             "data": "synthetic",
             "collectives": (td.get_backend() if dist else None),
             "config": {"workload": f"{n}x{n} / {k}-in-a-row self-play, {B} concurrent games per GPU, {S} sims/move "
-                                   f"{'(BASELINE.json configs[3] per-GPU shard)' if (n, k, S, B, a.model) == (15, 5, 400, 1024, 'plain') else '(custom)'}, {'GomokuNet' if a.model == 'plain' else 'ResidualBlock net'} random-init weights, numpy-compatible RNG tapes{', SUBTREE REUSE ON (not the reference algorithm)' if a.subtree_reuse else ''}{f', VIRTUAL-LOSS BATCHES OF {a.virtual_loss} (not the reference algorithm)' if a.virtual_loss > 1 else ''}{f', evaluation cache of {a.eval_cache} entries (results unchanged)' if a.eval_cache else ''}{', FP32-EMULATING TRUNK ON THE BF16 MATRIX CORES (opt-in: tolerance, not bit-exact)' if a.trunk != 'f32' else ''}",
+                                   f"{'(BASELINE.json configs[3] per-GPU shard)' if (n, k, S, B, a.model) == (15, 5, 400, 1024, 'plain') else '(custom)'}, {'GomokuNet' if a.model == 'plain' else 'ResidualBlock net'} random-init weights, numpy-compatible RNG tapes{', SUBTREE REUSE ON (not the reference algorithm)' if a.subtree_reuse else ''}{f', VIRTUAL-LOSS BATCHES OF {a.virtual_loss} (not the reference algorithm)' if a.virtual_loss > 1 else ''}{f', evaluation cache of {a.eval_cache} entries (results unchanged)' if a.eval_cache else ''}{f', FP32-EMULATING TRUNK ON THE 16-BIT MATRIX CORES, {a.trunk.upper()} (opt-in: tolerance, not bit-exact)' if a.trunk != 'f32' else ''}",
                        "board": n, "win_length": k, "sims_per_move": S, "games_per_gpu": B, "engines_per_gpu": a.engines,
                        "search_kernel": f"persistent ({persist} games per workgroup, trees in LDS)" if persist else "lock-step (k_trunk, k_fc, k_step per evaluation batch)", "parallelism": f"games sharded x{world}" + (" (ranks sharing GPUs, gloo rehearsal)" if share else "")},
             "per_gpu_node_expansions_per_sec": exp_all / dt / world,
@@ -293,8 +294,8 @@ def main():
             "episode": episode,
             "roofline": {"kernel": (f"k_search<{n},{persist}> (persistent: one launch per ply = {S + 1} x [encode+conv trunk+heads (MFMA), FC layers, tree step], "
                                     f"{persist} games per workgroup, trees in LDS; priced with the trunk FLOPs only)" if persist
-                                    else f"k_trunk_res_bf3<{n}> (encode+stem+3 residual blocks+head convs, LDS-resident; the 64->64 convs = 6 x v_mfma_f32_16x16x32_bf16 per tile and 32 k; peak = bf16 dense peak / 6)" if a.trunk != "f32" and a.model == "resnet"
-                                    else f"k_trunk_bf3<{n}> (encode+conv1+conv2+conv3+head convs, LDS-resident; conv2/conv3 = 6 x v_mfma_f32_16x16x32_bf16 per tile and 32 k; peak = bf16 dense peak / 6)" if a.trunk != "f32"
+                                    else f"k_trunk_res_emul<{n}, {a.trunk}> (encode+stem+3 residual blocks+head convs, LDS-resident; the 64->64 convs = {6 if a.trunk == 'bf16x3' else 3} x v_mfma_f32_16x16x32_{'bf16' if a.trunk == 'bf16x3' else 'f16'} per tile and 32 k; peak = 16-bit dense peak / {6 if a.trunk == 'bf16x3' else 3})" if a.trunk != "f32" and a.model == "resnet"
+                                    else f"k_trunk_emul<{n}, {a.trunk}> (encode+conv1+conv2+conv3+head convs, LDS-resident; conv2/conv3 = {6 if a.trunk == 'bf16x3' else 3} x v_mfma_f32_16x16x32_{'bf16' if a.trunk == 'bf16x3' else 'f16'} per tile and 32 k; peak = 16-bit dense peak / {6 if a.trunk == 'bf16x3' else 3})" if a.trunk != "f32"
                                     else f"k_trunk<{n}> (encode+conv1+conv2+conv3+head convs, LDS-resident, v_mfma_f32_16x16x4_f32)" if a.model == "plain"
                                     else f"k_trunk_res<{n}> (encode+stem+3 residual blocks+head convs, LDS-resident, v_mfma_f32_16x16x4_f32)"),
                          "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,

@@ -44,7 +44,7 @@ typedef enum {
 enum { AZ_EVAL_NET = 0, AZ_EVAL_SYNTHETIC = 1 };   /* synthetic = deterministic hash evaluator (test hook, mcts.py:87-93 seam) */
 enum { AZ_RES_NONE = 0, AZ_RES_X = 1, AZ_RES_O = 2, AZ_RES_DRAW = 3 }; /* constants.py:11-13 'X','O','D' */
 enum { AZ_AUG_REFERENCE4 = 4, AZ_AUG_DIHEDRAL8 = 8, AZ_AUG_NONE = 1 };
-enum { AZ_TRUNK_F32 = 0, AZ_TRUNK_BF16X3 = 1 };   /* arithmetic of the conv trunk, az_set_trunk_mode */
+enum { AZ_TRUNK_F32 = 0, AZ_TRUNK_BF16X3 = 1, AZ_TRUNK_F16X2 = 2 };   /* arithmetic of the conv trunk, az_set_trunk_mode */
 enum { AZ_MODEL_PLAIN = 0, AZ_MODEL_RESNET = 1 };  /* net.py GomokuNet | ResidualBlock variant (README.md:72) */
 
 /* Hyper-parameters the reference keeps in constants.py / MCTS.__init__ (mcts.py:87-97). */
@@ -275,14 +275,21 @@ int az_set_eval_cache(az_engine *e, int64_t entries);
  * az_search_callback.  Not allowed while an episode is open. */
 int az_set_leaf_symmetry(az_engine *e, int on);
 
-/* Opt-in: fp32-emulating conv trunk.  AZ_TRUNK_F32 (default) computes GomokuNet.forward (net.py:55-72) on the float32
- * matrix instruction in the build's canonical fp order: bit-identical to the oracle.  AZ_TRUNK_BF16X3 runs conv2 and conv3
- * (99 % of the net's arithmetic) on the 16 x faster bf16 matrix instruction with every operand split into three bf16 parts
- * and the six largest cross products accumulated in float32: float32-like accuracy (|logit| 2e-5, |P| 1e-6, |value| 2e-6
- * against the oracle, the tolerances already granted against the Python reference's torch numbers), NOT bit-identical, so
- * visit counts can differ from the reference's on near-tied PUCT scores.  One kernel for every occupancy (no split /
- * persistent variants), so results do not depend on the slot count.  GomokuNet only.  Invalidates the evaluation cache.
- * Not allowed while an episode is open. */
+/* Opt-in: fp32-emulating conv trunks.  AZ_TRUNK_F32 (default) computes the net's forward (net.py:55-72) on the float32
+ * matrix instruction in the build's canonical fp order: bit-identical to the oracle.  The other two run every conv but the
+ * first (99 % of the net's arithmetic) and the 1x1 head convs on the 16 x faster 16-bit matrix instructions with split
+ * operands and float32 accumulation:
+ *   AZ_TRUNK_BF16X3  three bfloat16 parts per operand, the six largest cross products: float32's exponent range, 2.67 x
+ *                    ceiling over the float32 instruction;
+ *   AZ_TRUNK_F16X2   two float16 parts per operand (the low part scaled by 2^11), three cross products in two accumulators:
+ *                    5.3 x ceiling; float16's range -- activations saturate at 65504 and a weight set with |w| >= 65504 is
+ *                    refused (AZ_ERR_INVALID from this call or from the next az_load_weights*, which puts the engine back on
+ *                    AZ_TRUNK_F32).
+ * Both give float32-like accuracy (|logit| 2e-5, |P| 1e-6, |value| 2e-6 against the oracle, the tolerances already granted
+ * against the Python reference's torch numbers), NOT bit-identical results, so visit counts can differ from the reference's
+ * on near-tied PUCT scores (measured: DESIGN.md section 4).  One kernel for every occupancy (no split / persistent variants),
+ * so results do not depend on the slot count.  Both nets.  Invalidates the evaluation cache.  Not allowed while an episode
+ * is open. */
 int az_set_trunk_mode(az_engine *e, int mode);
 int az_get_trunk_mode(const az_engine *e);
 

@@ -1,5 +1,5 @@
-"""GPU tests of the opt-in fp32-emulating conv trunk (az_set_trunk_mode(AZ_TRUNK_BF16X3), csrc/az_net_bf3.h), GomokuNet and
-the ResidualBlock variant.
+"""GPU tests of the opt-in fp32-emulating conv trunks (az_set_trunk_mode: AZ_TRUNK_BF16X3 and AZ_TRUNK_F16X2,
+csrc/az_net_emul.h), GomokuNet and the ResidualBlock variant.
 
 The mode trades the canonical fp order (bit-exact against the oracle) for the bf16 matrix cores, so its bar is a
 tolerance, the one the build already grants against the Python reference's torch numbers:
@@ -7,7 +7,7 @@ tolerance, the one the build already grants against the Python reference's torch
                                                                ResidualBlock net: |dvalue| <= 5e-6, its own torch bar)
 Everything integer stays exact given the evaluations: boards, legality, outcomes, z.  Visit counts CAN differ from the
 oracle's where two PUCT scores are closer than the evaluation error; the fraction of plies whose visit counts stay identical
-is measured, reported (gpurun_out/bf16x3_parity.json) and held above a floor.  The reference has no such mode: parity of
+is measured, reported (gpurun_out/emulated_trunk_parity.json) and held above a floor.  The reference has no such mode: parity of
 this mode is against the oracle only ("parity unpinned" by the reference).
 """
 import json
@@ -44,7 +44,7 @@ def _positions(n, count, seed):
 
 
 def _report(key, value):
-    path = os.path.join(ROOT, "gpurun_out", "bf16x3_parity.json")
+    path = os.path.join(ROOT, "gpurun_out", "emulated_trunk_parity.json")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         d = json.load(open(path)) if os.path.exists(path) else {}
@@ -66,17 +66,21 @@ def _net(n, tag):
     return sd, orc.Net(n, sd), "plain"
 
 
+MODES = ["bf16x3", "f16x2"]
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("n,k,tag", [(5, 4, "seeded"), (5, 4, "ckpt_saved"), (9, 5, "seeded"), (15, 5, "seeded"),
                                      (5, 4, "resnet"), (9, 5, "resnet"), (15, 5, "resnet")])
-def test_net_outputs_within_tolerance_of_the_oracle(n, k, tag):
+def test_net_outputs_within_tolerance_of_the_oracle(n, k, tag, mode):
     sd, onet, model = _net(n, tag)
     boards, players, lasts = _positions(n, 96, 7 + n)
     o = orc.Oracle(n, k, 1)
     e = az.Engine(n, k, 8, 40, model=model)          # 96 positions in three passes of 40 / 40 / 16 boards
     e.load_weights(sd, 0)
     l32, p32, v32 = e.net_eval(boards, players, lasts)
-    e.set_trunk_mode("bf16x3")
-    assert e.trunk_mode() == "bf16x3"
+    e.set_trunk_mode(mode)
+    assert e.trunk_mode() == mode
     lem, pem, vem = e.net_eval(boards, players, lasts)
     e.set_trunk_mode("f32")
     l32b, p32b, v32b = e.net_eval(boards, players, lasts)
@@ -90,7 +94,7 @@ def test_net_outputs_within_tolerance_of_the_oracle(n, k, tag):
         dl = max(dl, float(np.abs(lem[i] - lo.reshape(-1)).max()))
         dp = max(dp, float(np.abs(pem[i] - Po.reshape(-1)).max()))
         dv = max(dv, float(abs(float(vem[i]) - float(vo))))
-    _report(f"net_{n}x{n}_{tag}", {"max_abs_dlogit": dl, "max_abs_dP": dp, "max_abs_dvalue": dv, "positions": len(boards)})
+    _report(f"{mode}_net_{n}x{n}_{tag}", {"max_abs_dlogit": dl, "max_abs_dP": dp, "max_abs_dvalue": dv, "positions": len(boards)})
     # the ResidualBlock net's bar for the value is the one tests/test_resnet_gpu.py grants the exact-order kernel against the
     # build's torch module (5e-6): seven stacked convs and a skip path instead of three convs
     tol_v = 5e-6 if model == "resnet" else TOL_V
@@ -100,8 +104,9 @@ def test_net_outputs_within_tolerance_of_the_oracle(n, k, tag):
     assert dl > 0.0, "the emulated trunk returned the canonical bits: the mode switch did nothing"
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("n,k,S,G,maxply,tag", [(9, 5, 200, 6, 0, "seeded"), (15, 5, 400, 4, 24, "seeded"), (15, 5, 200, 3, 12, "resnet")])
-def test_selfplay_in_emulated_mode_against_the_oracle(n, k, S, G, maxply, tag):
+def test_selfplay_in_emulated_mode_against_the_oracle(n, k, S, G, maxply, tag, mode):
     """Games played with the emulated trunk: rules, records and z exact; every ply searched again by the oracle (exact
     float32 order) from the recorded position with the same tape -- the fraction of plies whose visit counts are
     identical is reported and must stay above a floor; pi agrees within 1e-6 on those plies."""
@@ -111,7 +116,7 @@ def test_selfplay_in_emulated_mode_against_the_oracle(n, k, S, G, maxply, tag):
     sd, onet, model = _net(n, tag)
     e = az.Engine(n, k, S, G, log_table=orc.numpy_log_table(S), model=model)
     e.load_weights(sd, 0)
-    e.set_trunk_mode("bf16x3")
+    e.set_trunk_mode(mode)
     c = e.selfplay(G, seed0=seed0, max_plies=maxply)
     assert e.persistent() == 0
     rec = e.records(); nply, res = e.games()
@@ -152,27 +157,46 @@ def test_selfplay_in_emulated_mode_against_the_oracle(n, k, S, G, maxply, tag):
                 max_dpi = max(max_dpi, float(np.abs(rec["pis"][ri] - r["pi"]).max()))
             same_action += int(rec["actions"][ri]) == r["action"]
     frac = same / total
-    _report(f"selfplay_{n}x{n}_S{S}_{tag}", {"plies": total, "plies_with_identical_visit_counts": same, "fraction": frac,
+    _report(f"{mode}_selfplay_{n}x{n}_S{S}_{tag}", {"plies": total, "plies_with_identical_visit_counts": same, "fraction": frac,
                                         "plies_with_identical_move": same_action, "max_abs_dpi_on_identical_plies": max_dpi})
-    print(f"bf16x3 {tag} {n}x{n} S={S}: {same}/{total} plies with visit counts identical to the exact-order oracle "
+    print(f"{mode} {tag} {n}x{n} S={S}: {same}/{total} plies with visit counts identical to the exact-order oracle "
           f"({frac:.3f}), same move on {same_action}, max |dpi| {max_dpi:.2e}")
     assert frac >= 0.75, f"only {same}/{total} plies kept the oracle's visit counts"
     assert max_dpi <= 1e-6
 
 
-def test_selfplay_manager_with_the_emulated_trunk():
-    """The drop-in seam: SelfPlayManager(trunk="bf16x3") returns the reference's (state, pi, z) contract."""
+@pytest.mark.parametrize("mode", MODES)
+def test_selfplay_manager_with_the_emulated_trunk(mode):
+    """The drop-in seam: SelfPlayManager(trunk=...) returns the reference's (state, pi, z) contract."""
     import torch
     from alphazero_piskvorky_amd.controller import NeuralNetworkController
     from alphazero_piskvorky_amd.net import GomokuNet
     from alphazero_piskvorky_amd.self_play import SelfPlayManager
     torch.manual_seed(0)
     ctl = NeuralNetworkController(GomokuNet(board_size=5), device="cuda:0")
-    ex = SelfPlayManager(ctl, "cuda:0", mcts_params={"num_simulations": 20}, seed=5, trunk="bf16x3").generate_self_play(6)
+    ex = SelfPlayManager(ctl, "cuda:0", mcts_params={"num_simulations": 20}, seed=5, trunk=mode).generate_self_play(6)
     assert len(ex) % 4 == 0 and len(ex) >= 6 * 4 * 7
     st, pi, z = ex[0]
     assert tuple(st.shape) == (4, 5, 5) and pi.shape == (5, 5) and z in (-1, 0, 1)
     assert abs(float(pi.sum()) - 1.0) < 1e-5
+
+
+def test_float16_range_is_enforced():
+    """AZ_TRUNK_F16X2 refuses weights outside float16's range, whichever comes first, the switch or the load."""
+    sd = dict(build_weights(5))
+    bad = {k: v.copy() for k, v in sd.items()}
+    bad["conv3.weight"][3, 5, 1, 1] = 7.0e4
+    e = az.Engine(5, 4, 8, 2)
+    e.load_weights(bad, 0)
+    with pytest.raises(_capi.AzError):
+        e.set_trunk_mode("f16x2")
+    e.set_trunk_mode("bf16x3")             # float32's exponent range: fine
+    e.load_weights(sd, 0)
+    e.set_trunk_mode("f16x2")
+    with pytest.raises(_capi.AzError):
+        e.load_weights(bad, 0)             # ... and the engine falls back to the float32 trunk
+    assert e.trunk_mode() == "f32"
+    e.close()
 
 
 def test_mode_errors():
