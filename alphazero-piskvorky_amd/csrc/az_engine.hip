@@ -33,7 +33,7 @@ struct PackedNet {
     bool loaded = false;
     DevBuf c1, c2, c3, hd, pf, vf, c1b, c2b, c3b, hdb, pfb, vfb, v2w, v2b;
     DevBuf rblk[6], rblkb[6];          // ResidualBlock variant: the six 64->64 convs (c1/c1b hold the stem)
-    DevBuf c2x[2], c3x[2], hdx[2];     // conv2 / conv3 / head convs split into 16-bit MFMA fragments (az_net_emul.h): [0] bf16x3, [1] f16x2
+    DevBuf c1x[2], c2x[2], c3x[2], hdx[2];     // the convs (c1x: conv1 / stem) and head convs split into 16-bit MFMA fragments (az_net_emul.h): [0] bf16x3, [1] f16x2
     DevBuf rblkx[2][6];                // ... and the six 64 -> 64 convs of the ResidualBlock variant
     bool f16_ok = true;                // every weight of the emulated layers is inside float16's range (AZ_TRUNK_F16X2)
     NetWeights w{};
@@ -275,6 +275,24 @@ static inline bool emul_split(int scheme, float x, uint16_t *parts)
     parts[1] = bf16_rne(r1);
     parts[2] = bf16_rne(r1 - bf16_val(parts[1]));
     return true;
+}
+// the first conv (cin = 4, K = 36 padded to two K-blocks of 32): k = tap * 4 + plane
+static std::vector<uint16_t> pack_first_emul(int scheme, const float *w, int cout, bool *ok)
+{
+    const int ns = emul_parts(scheme), nt = cout / 16;
+    std::vector<uint16_t> out((size_t)nt * 2 * ns * 64 * 8, 0);
+    for (int t = 0; t < nt; t++)
+        for (int kb = 0; kb < 2; kb++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const int k = kb * 32 + 8 * (lane >> 4) + j, co = t * 16 + (lane & 15);
+                    if (k >= 36) continue;
+                    uint16_t parts[3];
+                    if (!emul_split(scheme, w[((size_t)co * 4 + (k & 3)) * 9 + (k >> 2)], parts)) *ok = false;
+                    const size_t base = (((size_t)t * 2 + kb) * ns * 64 + lane) * 8 + j;
+                    for (int s2 = 0; s2 < ns; s2++) out[base + (size_t)s2 * 64 * 8] = parts[s2];
+                }
+    return out;
 }
 static std::vector<uint16_t> pack_conv_emul(int scheme, const float *w, int cout, int cin, bool *ok)
 {
@@ -659,7 +677,7 @@ extern "C" void az_destroy(az_engine *e)
     for (DevBuf *b : shared) dev_free(*b);
     for (int s = 0; s < 2; s++) {
         PackedNet &p = e->net[s];
-        DevBuf *nb[] = {&p.c1, &p.c2, &p.c3, &p.hd, &p.pf, &p.vf, &p.c1b, &p.c2b, &p.c3b, &p.hdb, &p.pfb, &p.vfb, &p.v2w, &p.v2b, &p.c2x[0], &p.c2x[1], &p.c3x[0], &p.c3x[1], &p.hdx[0], &p.hdx[1]};
+        DevBuf *nb[] = {&p.c1, &p.c2, &p.c3, &p.hd, &p.pf, &p.vf, &p.c1b, &p.c2b, &p.c3b, &p.hdb, &p.pfb, &p.vfb, &p.v2w, &p.v2b, &p.c1x[0], &p.c1x[1], &p.c2x[0], &p.c2x[1], &p.c3x[0], &p.c3x[1], &p.hdx[0], &p.hdx[1]};
         for (DevBuf *b : nb) dev_free(*b);
         for (int i = 0; i < 6; i++) { dev_free(p.rblk[i]); dev_free(p.rblkb[i]); dev_free(p.rblkx[0][i]); dev_free(p.rblkx[1][i]); }
     }
@@ -686,6 +704,8 @@ extern "C" int az_load_weights(az_engine *e, int slot, const float *const *t)
     p.f16_ok = true;
     for (int sch = AZ_TRUNK_BF16X3; sch <= AZ_TRUNK_F16X2 && !rc; sch++) {
         bool ok = true;
+        const std::vector<uint16_t> x1 = pack_first_emul(sch, t[0], 32, &ok);
+        if (!rc) rc = upload(e, p.c1x[sch - 1], x1.data(), x1.size() * 2);
         const std::vector<uint16_t> x2 = pack_conv_emul(sch, t[2], 64, 32, &ok), x3 = pack_conv_emul(sch, t[4], 128, 64, &ok);
         const std::vector<uint16_t> xh = pack_heads_emul(sch, t[6], 4, t[10], 2, 128, &ok);
         if (!rc) rc = upload(e, p.c2x[sch - 1], x2.data(), x2.size() * 2);
@@ -704,7 +724,7 @@ extern "C" int az_load_weights(az_engine *e, int slot, const float *const *t)
     p.w.hd = (const float *)p.hd.p; p.w.pf = (const float *)p.pf.p; p.w.vf = (const float *)p.vf.p;
     p.w.c1b = (const float *)p.c1b.p; p.w.c2b = (const float *)p.c2b.p; p.w.c3b = (const float *)p.c3b.p;
     p.w.hdb = (const float *)p.hdb.p; p.w.pfb = (const float *)p.pfb.p; p.w.vfb = (const float *)p.vfb.p;
-    for (int i = 0; i < 2; i++) { p.w.c2x[i] = p.c2x[i].p; p.w.c3x[i] = p.c3x[i].p; p.w.hdx[i] = p.hdx[i].p; }
+    for (int i = 0; i < 2; i++) { p.w.c1x[i] = p.c1x[i].p; p.w.c2x[i] = p.c2x[i].p; p.w.c3x[i] = p.c3x[i].p; p.w.hdx[i] = p.hdx[i].p; }
     e->cache_gen++;           // evaluations cached under the previous weights never match again
     each_state(e, [&](DevState &d) { d.v2w[slot] = (const float *)p.v2w.p; d.v2b[slot] = (const float *)p.v2b.p; d.cache_gen = e->cache_gen; });
     p.loaded = true;
@@ -732,6 +752,8 @@ extern "C" int az_load_weights_resnet(az_engine *e, int slot, const float *const
     p.f16_ok = true;
     for (int sch = AZ_TRUNK_BF16X3; sch <= AZ_TRUNK_F16X2 && !rc; sch++) {
         bool ok = true;
+        const std::vector<uint16_t> x1 = pack_first_emul(sch, t[0], 64, &ok);
+        rc = upload(e, p.c1x[sch - 1], x1.data(), x1.size() * 2);
         for (int i = 0; i < 6 && !rc; i++) {
             const std::vector<uint16_t> x = pack_conv_emul(sch, t[2 + 2 * i], 64, 64, &ok);
             rc = upload(e, p.rblkx[sch - 1][i], x.data(), x.size() * 2);
@@ -753,6 +775,7 @@ extern "C" int az_load_weights_resnet(az_engine *e, int slot, const float *const
     for (int sch = 0; sch < 2; sch++) {
         for (int i = 0; i < 6; i++) p.rw.blkx[sch][i] = p.rblkx[sch][i].p;
         p.rw.hdx[sch] = p.hdx[sch].p;
+        p.rw.stemx[sch] = p.c1x[sch].p;
     }
     p.w = NetWeights{};
     p.w.pf = (const float *)p.pf.p; p.w.vf = (const float *)p.vf.p;

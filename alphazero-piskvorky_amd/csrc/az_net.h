@@ -34,7 +34,7 @@ struct NetWeights {
     // MFMA-fragment packed (see pack_* in az_engine.hip): [ntile][kstep/4][lane][4]
     const float *c1, *c2, *c3, *hd, *pf, *vf;
     const float *c1b, *c2b, *c3b, *hdb, *pfb, *vfb;   // biases (hdb: 4 policy_conv + 2 value_conv)
-    const void *c2x[2], *c3x[2], *hdx[2];             // conv2 / conv3 / head convs split into 16-bit fragments (az_net_emul.h), [0] bf16x3, [1] f16x2
+    const void *c1x[2], *c2x[2], *c3x[2], *hdx[2];    // the convs and head convs split into 16-bit fragments (az_net_emul.h), [0] bf16x3, [1] f16x2
 };
 
 __host__ __device__ constexpr int up16(int x) { return x + ((16 - (x % 32) + 32) % 32); }   // smallest y >= x, y == 16 (mod 32)
@@ -618,7 +618,7 @@ struct ResWeights {
     const float *stem, *stemb;
     const float *blk[6], *blkb[6];     // res1.conv1, res1.conv2, res2.conv1, ... (MFMA-fragment packed), folded biases
     const float *hd, *hdb;             // policy_conv (2) + value_conv (1) rows of one 16-row tile, folded biases [3]
-    const void *blkx[2][6], *hdx[2];   // the six 64 -> 64 convs and the head rows split into 16-bit fragments (az_net_emul.h), [0] bf16x3, [1] f16x2
+    const void *stemx[2], *blkx[2][6], *hdx[2];   // stem, the six 64 -> 64 convs and the head rows split into 16-bit fragments (az_net_emul.h), [0] bf16x3, [1] f16x2
 };
 
 template <int N>

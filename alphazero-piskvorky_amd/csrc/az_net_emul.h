@@ -15,8 +15,8 @@
 //                    stay below it (checked at az_load_weights) -- a net beyond that belongs to the other modes.
 // NOT the canonical fp order: results agree with the oracle within a tolerance (tests/test_emulated_trunk_gpu.py: logits 2e-5,
 // P 1e-6, value 2e-6 -- the tolerances the build already grants against the Python reference's torch numbers), not bit for
-// bit, so neither is ever the default.  The first conv (K = 36, 1 % of the work) stays on the f32 MFMA; the other convs and
-// the 1x1 head convs run on the 16-bit MFMA.
+// bit, so neither is ever the default.  Every conv and the 1x1 head convs run on the 16-bit MFMA (the first conv's 0 / 1
+// input planes are exact in one part, so only its weights are split).
 //
 // LDS images: an activation image is a list of PLANES of CS 16-byte slots; plane (NS * (ci/8) + part), slot = position in the
 // zero-padded board image, 8 consecutive channels per slot -- exactly the B fragment of one lane (k = 8 (lane >> 4) + j), so
@@ -83,6 +83,7 @@ template <> struct Emul<EMUL_BF16X3> {
         return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
     }
     __device__ static __forceinline__ float fold(float a, float) { return a; }
+    static constexpr unsigned ONE = 0x3F80u;       // 1.0 in bfloat16
 };
 template <> struct Emul<EMUL_F16X2> {
     static constexpr int NS = 2, NP = 3, NACC = 2;
@@ -111,6 +112,7 @@ template <> struct Emul<EMUL_F16X2> {
         return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
     }
     __device__ static __forceinline__ float fold(float a, float ax) { return a + ax * (1.0f / 2048.0f); }
+    static constexpr unsigned ONE = 0x3C00u;       // 1.0 in float16
 };
 
 // v[0..3] = channels co .. co+3 (co % 4 == 0) at padded position pos -> the part planes of channel group co / 8
@@ -129,39 +131,47 @@ __device__ __forceinline__ void store_parts(uint2 *img, int co, int pos, const f
 // or a layer ahead) so that no L2 round trip sits on the critical path between the layers.
 template <int SCH>
 struct EmulPre {
-    float4 c1w[3];          // conv1: the 9 k-steps of the wave's channel tile (f32 MFMA fragments)
+    uint4 c1w[2][Emul<SCH>::NS];   // conv1: the two K-blocks of the wave's channel tile, one fragment per part
     float b1[4], b2[4], b3[4];   // biases of the wave's channel tile in conv1 / conv2 / conv3, rows 4 (lane >> 4) .. + 3
     uint2 hw[Emul<SCH>::NS];     // head-conv fragments of the wave's conv3 tile, one per part
 };
 
-// The first conv (4 -> COUT, K = 36: GomokuNet's conv1, the ResidualBlock net's stem) on the f32 MFMA like az_net.h's
-// conv_layer<.., 4, COUT, ..>, output split into the COUT-channel image; keep != nullptr also returns the wave's tiles as
+// The first conv (4 -> COUT, K = 36 = 9 taps x 4 planes: GomokuNet's conv1, the ResidualBlock net's stem) on the 16-bit MFMA.
+// Its input -- the encode planes of games.py:86-129 -- is 0 / 1, exact in one 16-bit part, so only the weights are split: NS
+// products per tile and K-block, K padded to 64.  The input image is [position][4 planes] of 16-bit values (8 bytes per
+// padded position); lane (q, cell) holds k = 8 q + j = taps 2 q and 2 q + 1 of K-block 0 (two 8-byte reads at the taps'
+// offsets) and tap 8 of K-block 1 (q = 0 only).  w: [tile][K-block][part][lane][8], zero beyond k = 36 (requested by the
+// caller before the prologue).  Output split into the COUT-channel image; keep != nullptr also returns the wave's tiles as
 // float32 (the skip connection's operand of the first residual block).
 template <class G, int COUT, int SCH>
-__device__ __forceinline__ void conv_first_emul(const float *in, uint2 *out, const float4 (&c1w)[3], const float (&b1)[4],
-                                               const unsigned short *wpos, const unsigned short *cellof, int wave, int lane,
-                                               f32x4 *keep = nullptr)
+__device__ __forceinline__ void conv_first_emul(const uint2 *in, uint2 *out, const uint4 (&w)[2][Emul<SCH>::NS], const float (&b1)[4],
+                                                const unsigned short *wpos, const unsigned short *cellof, int wave, int lane,
+                                                f32x4 *keep = nullptr)
 {
+    typedef Emul<SCH> E;
     constexpr int NG = COUT / 16, MG = G::NW / NG, MTW = (G::MT + MG - 1) / MG;
     static_assert(NG * MG == G::NW, "wave grid does not cover the workgroup");
     const int ng = wave % NG, mg = wave / NG;
     const int q = lane >> 4, r16 = lane & 15;
-    f32x4 acc[MTW];
-    int rb[MTW];
+    const int t0 = 2 * q, t1 = 2 * q + 1;
+    const int off0 = (t0 / 3) * G::PW + (t0 % 3), off1 = (t1 / 3) * G::PW + (t1 % 3), off8 = 2 * G::PW + 2;
+    f32x4 acc[E::NACC][MTW];
 #pragma unroll
     for (int i = 0; i < MTW; i++) {
-        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int mt = mg + i * MG;
         const int m = (mt < G::MT ? mt : 0) * 16 + r16;        // a surplus tile aliases tile 0 (computed, never written back)
-        rb[i] = (int)wpos[m] - (G::PW + 1) + q * G::CS;
-    }
-    const float bk[12] = {c1w[0].x, c1w[0].y, c1w[0].z, c1w[0].w, c1w[1].x, c1w[1].y, c1w[1].z, c1w[1].w,
-                          c1w[2].x, c1w[2].y, c1w[2].z, c1w[2].w};
+        const int base = (int)wpos[m] - (G::PW + 1);
+        const uint2 a0 = in[base + off0], a1 = in[base + off1], a8 = in[base + off8];
+        const uint4 f0 = uint4{a0.x, a0.y, a1.x, a1.y};
+        const uint4 f1 = q == 0 ? uint4{a8.x, a8.y, 0u, 0u} : uint4{0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int tap = 0; tap < 9; tap++) {
-        const int toff = (tap / 3) * G::PW + (tap % 3);
+        for (int a = 0; a < E::NACC; a++) acc[a][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < MTW; i++) acc[i] = mfma4(bk[tap], in[rb[i] + toff], acc[i]);
+        for (int s = E::NS - 1; s >= 0; s--) {                  // small parts first; part s > 0 of the float16 scheme feeds the scaled accumulator
+            const int ai = (E::NACC > 1 && s > 0) ? 1 : 0;
+            acc[ai][i] = E::mfma32(w[0][s], f0, acc[ai][i]);
+            acc[ai][i] = E::mfma32(w[1][s], f1, acc[ai][i]);
+        }
     }
 #pragma unroll
     for (int i = 0; i < MTW; i++) {
@@ -169,7 +179,7 @@ __device__ __forceinline__ void conv_first_emul(const float *in, uint2 *out, con
         float v[4];
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
-            const float x = acc[i][rg] + b1[rg];
+            const float x = E::fold(acc[0][i][rg], acc[E::NACC - 1][i][rg]) + b1[rg];
             v[rg] = x > 0.0f ? x : 0.0f;
         }
         if (keep) keep[i] = f32x4{v[0], v[1], v[2], v[3]};
@@ -372,9 +382,8 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk_emul(DevState d, NetWeight
     const uint4 *c2x = reinterpret_cast<const uint4 *>(w.c2x[SCH - 1]), *c3x = reinterpret_cast<const uint4 *>(w.c3x[SCH - 1]);
     {
         const int q = lane >> 4;
-        const float4 *c1 = reinterpret_cast<const float4 *>(w.c1) + (size_t)(wave % 2) * 3 * 64 + lane;
-#pragma unroll
-        for (int j = 0; j < 3; j++) pre.c1w[j] = c1[j * 64];
+        emul_weights<2, NS>(reinterpret_cast<const uint4 *>(w.c1x[SCH - 1]), wave % 2, 0, lane, pre.c1w[0]);
+        emul_weights<2, NS>(reinterpret_cast<const uint4 *>(w.c1x[SCH - 1]), wave % 2, 1, lane, pre.c1w[1]);
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
             pre.b1[rg] = w.c1b[(wave % 2) * 16 + q * 4 + rg];
@@ -386,9 +395,9 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk_emul(DevState d, NetWeight
         for (int s = 0; s < NS; s++) pre.hw[s] = hx[s * 64];
         emul_weights<9, NS>(c2x, wave % 4, 0, lane, w2);
     }
-    // region X = 8 NS planes of CS slots: conv1 out in the first 4 NS planes, conv2 out in all of them; the float32 input
-    // planes of conv1 are the bytes of plane 4 NS
-    float *inP = lds + 16 * NS * G::CS;
+    // region X = 8 NS planes of CS slots: conv1 out in the first 4 NS planes, conv2 out in all of them; conv1's input image
+    // ([position][4 planes] of 16-bit values, 8 bytes per position) is the first half of plane 4 NS
+    uint2 *inP = reinterpret_cast<uint2 *>(lds + 16 * NS * G::CS);
     // Every thread requests the leaf words of its cells (games.py:86-129 encode) before it is known whether the group has
     // anything to evaluate: the loads are in flight while the image is zeroed.
     constexpr int EPT = (G::MR + NTH - 1) / NTH;
@@ -432,17 +441,15 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk_emul(DevState d, NetWeight
     __syncthreads();
     if (!any_active) return;
 #pragma unroll
-    for (int e = 0; e < EPT; e++) {
-        if (e_me[e]) inP[e_pos[e]] = 1.0f;
-        if (e_op[e]) inP[G::CS + e_pos[e]] = 1.0f;
-        if (e_last[e]) inP[2 * G::CS + e_pos[e]] = 1.0f;
-    }
+    for (int e = 0; e < EPT; e++)
+        if (e_me[e] || e_op[e] || e_last[e])
+            inP[e_pos[e]] = uint2{(e_me[e] ? E::ONE : 0u) | (e_op[e] ? E::ONE << 16 : 0u), e_last[e] ? E::ONE : 0u};
     __syncthreads();
     AZ_STAMP(1);
     conv_first_emul<G, 32, SCH>(inP, reinterpret_cast<uint2 *>(lds), pre.c1w, pre.b1, wpos, cellof, wave, lane);
     emul_weights<18, NS>(c3x, wave, 0, lane, w3);       // conv3's first K-block, a layer ahead
     __syncthreads();
-    for (int i = tid; i < 3 * G::CS; i += NTH) inP[i] = 0.0f;      // the input planes' bytes are part of conv2's output image
+    for (int i = tid; i < G::CS; i += NTH) inP[i] = uint2{0u, 0u};      // the input image's bytes are part of conv2's output image
     AZ_STAMP(2);
     conv_layer_emul<G, 32, 64, BF3_OUT_IMAGE, 6, SCH>(reinterpret_cast<const uint4 *>(lds), lds, c2x, w2, pre.b2, pre.hw, wpos, cellof, wave, lane);
     __syncthreads();
@@ -495,7 +502,7 @@ __global__ __launch_bounds__(ResGeoEmul<N>::NW * 64) void k_trunk_res_emul(DevSt
     constexpr int NTH = G::NW * 64, NS = E::NS;
     constexpr int NG = 4, MG = G::NW / NG, MTW = (G::MT + MG - 1) / MG, NH = G::PC + G::VC;
     constexpr int XF = 32 * NS * G::CS;          // floats of the 64-channel image
-    static_assert(XF + 4 * G::CS <= G::LDSF && NG * NH * G::MR <= XF, "LDS layout of the emulated ResidualBlock trunk");
+    static_assert(XF + 2 * G::CS <= G::LDSF && NG * NH * G::MR <= XF, "LDS layout of the emulated ResidualBlock trunk");
     __shared__ __attribute__((aligned(16))) float lds[G::LDSF];
     __shared__ unsigned short wpos[G::MR];
     __shared__ unsigned short cellof[G::MR];
@@ -514,15 +521,14 @@ __global__ __launch_bounds__(ResGeoEmul<N>::NW * 64) void k_trunk_res_emul(DevSt
         }
     }
     // requests that depend on nothing: stem fragments and bias, the first conv's first K-block and bias
-    float4 c1w[3];
+    uint4 c1w[2][NS];
     float bcur[4], bnxt[4];
     uint2 hw[NS];
     uint4 wcur[NS], wnxt[NS];
     const void *const *blkx = w.blkx[SCH - 1];
     {
-        const float4 *c1 = reinterpret_cast<const float4 *>(w.stem) + (size_t)ng * 3 * 64 + lane;
-#pragma unroll
-        for (int j = 0; j < 3; j++) c1w[j] = c1[j * 64];
+        emul_weights<2, NS>(reinterpret_cast<const uint4 *>(w.stemx[SCH - 1]), ng, 0, lane, c1w[0]);
+        emul_weights<2, NS>(reinterpret_cast<const uint4 *>(w.stemx[SCH - 1]), ng, 1, lane, c1w[1]);
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) bcur[rg] = w.stemb[ng * 16 + q * 4 + rg];
 #pragma unroll
@@ -531,8 +537,8 @@ __global__ __launch_bounds__(ResGeoEmul<N>::NW * 64) void k_trunk_res_emul(DevSt
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) bnxt[rg] = w.blkb[0][ng * 16 + q * 4 + rg];
     }
-    // the 64-channel split image = 8 NS planes of CS slots; the stem's float32 input planes behind it
-    float *inP = lds + XF;
+    // the 64-channel split image = 8 NS planes of CS slots; the stem's input image ([position][4 planes], 16-bit) behind it
+    uint2 *inP = reinterpret_cast<uint2 *>(lds + XF);
     constexpr int EPT = (G::MR + NTH - 1) / NTH;
     int e_pos[EPT];
     bool e_me[EPT], e_op[EPT], e_last[EPT];
@@ -569,16 +575,14 @@ __global__ __launch_bounds__(ResGeoEmul<N>::NW * 64) void k_trunk_res_emul(DevSt
     }
     {
         float4 *z = reinterpret_cast<float4 *>(lds);
-        for (int i = tid; i < (XF + 4 * G::CS) / 4; i += NTH) z[i] = float4{0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < (XF + 2 * G::CS) / 4; i += NTH) z[i] = float4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
     if (!any_active) return;
 #pragma unroll
-    for (int e = 0; e < EPT; e++) {
-        if (e_me[e]) inP[e_pos[e]] = 1.0f;
-        if (e_op[e]) inP[G::CS + e_pos[e]] = 1.0f;
-        if (e_last[e]) inP[2 * G::CS + e_pos[e]] = 1.0f;
-    }
+    for (int e = 0; e < EPT; e++)
+        if (e_me[e] || e_op[e] || e_last[e])
+            inP[e_pos[e]] = uint2{(e_me[e] ? E::ONE : 0u) | (e_op[e] ? E::ONE << 16 : 0u), e_last[e] ? E::ONE : 0u};
     __syncthreads();
     f32x4 keep[MTW];
     const uint4 *X = reinterpret_cast<const uint4 *>(lds);

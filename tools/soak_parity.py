@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Full-size parity soak (not part of the regular suite: minutes of host time): complete self-play games at the BASELINE
 configuration, engine vs the CPU oracle, every ply of every game bit for bit (boards, visit counts, pi, actions, z).
-usage: soak_parity.py [games] [model plain|resnet] [sims] [out.json|-] [board] [reuse] [ckpt] [bf16x3]
-bf16x3 = the opt-in emulated trunk: reports how many free-running games (and plies before the first difference) stay identical
+usage: soak_parity.py [games] [model plain|resnet] [sims] [out.json|-] [board] [reuse] [ckpt] [bf16x3|f16x2]
+bf16x3 / f16x2 = an opt-in emulated trunk: reports how many free-running games (and plies before the first difference) stay identical
 to the exact-order oracle instead of demanding all of them."""
 import json, os, sys, time
 from concurrent.futures import ThreadPoolExecutor
@@ -19,7 +19,7 @@ S = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 out = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] != "-" else None
 n = int(sys.argv[5]) if len(sys.argv) > 5 else 15          # optional: board size, "reuse" for subtree reuse, "ckpt" = trained 5x5 weights
 reuse = "reuse" in sys.argv[6:]
-emul = "bf16x3" in sys.argv[6:]
+emul = "bf16x3" if "bf16x3" in sys.argv[6:] else ("f16x2" if "f16x2" in sys.argv[6:] else None)
 k, seed0 = (4 if n <= 5 else 5), 1_000_000
 if "ckpt" in sys.argv[6:]:
     from tests.util import weights_from_fixture
@@ -31,7 +31,7 @@ eng = az.Engine(n, k, S, slots, log_table=orc.numpy_log_table(S), model=model)
 eng.load_weights(sd, 0)
 eng.set_subtree_reuse(reuse)
 if emul:
-    eng.set_trunk_mode("bf16x3")
+    eng.set_trunk_mode(emul)
 t0 = time.perf_counter()
 c = eng.selfplay(G, seed0=seed0)
 t_gpu = time.perf_counter() - t0
@@ -62,7 +62,7 @@ summary = {"config": f"{n}x{n}/{k}, {S} sims, {model} net{' (trained 5x5 checkpo
            "games_bit_exact": G - len(fails), "games": G, "gpu_seconds": round(t_gpu, 2), "oracle_seconds": round(t_cpu, 1),
            "oracle_threads": os.cpu_count(), "compared": "actions, boards, movers, visit counts, pi (f32 bit patterns), z, last moves, per ply"}
 if emul:
-    summary["trunk"] = "bf16x3 (opt-in emulated trunk: tolerance, not bit-exact)"
+    summary["trunk"] = emul + " (opt-in emulated trunk: tolerance, not bit-exact)"
     summary["plies_identical_before_first_difference"] = int(sum(r[7] for r in rows))
     summary["games_with_identical_visit_counts_throughout"] = int(sum(1 for r in rows if r[7] == r[1] == r[2]))
 print(json.dumps(summary))

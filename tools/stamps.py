@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: phase breakdown of k_trunk / k_trunk_bf3 from s_memtime stamps (build with `make EXTRA=-DAZ_STAMPS`):
-python tools/stamps.py [board] [f32|bf16x3]"""
+"""Diagnostic: phase breakdown of k_trunk / k_trunk_emul from s_memtime stamps (build with `make EXTRA=-DAZ_STAMPS`):
+python tools/stamps.py [board] [f32|bf16x3|f16x2]"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
