@@ -232,16 +232,12 @@ def main():
         try:
             if a.model != "plain":
                 raise KeyError("no PMC pass for this kernel yet")
-            if a.trunk == "f32":
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))[f"k_trunk<{n}>"]
-                traffic = pm["hbm_bytes_per_board"] * boards / launches
-                traffic_src = "profiles/r01_pmc_summary.json (separate --pmc passes, per board x boards per launch)"
-            elif a.trunk == "bf16x3":
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bf16x3_summary.json")))[f"k_trunk_bf3<{n}>"]
-                # FETCH_SIZE / WRITE_SIZE in KiB per dispatch; FETCH_SIZE doubled per the gfx950 note (16-B-per-lane streams count half)
-                per_board = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0 / (pm["grid"] / pm["workgroup"])
-                traffic = per_board * boards / launches
-                traffic_src = "profiles/r02_pmc_bf16x3_summary.json (separate --pmc passes, per board x boards per launch)"
+            key = f"k_trunk<{n}>" if a.trunk == "f32" else f"k_trunk_emul<{n}, {1 if a.trunk == 'bf16x3' else 2}>"
+            pm = json.load(open(os.path.join(ROOT, "profiles", f"r02_pmc_{a.trunk}_summary.json")))[key]
+            # FETCH_SIZE / WRITE_SIZE in KiB per dispatch; FETCH_SIZE doubled per the gfx950 note (16-B-per-lane streams count half)
+            per_board = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0 / (pm["grid"] / pm["workgroup"])
+            traffic = per_board * boards / launches
+            traffic_src = f"profiles/r02_pmc_{a.trunk}_summary.json (separate --pmc passes, per board x boards per launch)"
         except Exception:
             pass
         # the rest of the path, priced against HBM with SURVEY 8(d)'s algorithmic bytes (reference semantics, fp32 edges):
