@@ -59,6 +59,7 @@ struct Lane {
     std::vector<hipEvent_t> ev;    // profiling events
     // progress of the open episode
     int active = 0;                // active slots after the last refill
+    int cur = 0;                   // slots the next ply is launched over: all of them, or (after a compacting refill) the active ones
     int plies_played = 0;          // plies this lane has played in the open episode
     int64_t steps = 0, trunk_launches = 0, plies = 0;
     double trunk_ms = 0.0, nn_ms = 0.0, step_ms = 0.0;
@@ -102,6 +103,7 @@ struct az_engine {
     } run;
     bool profile = false;          // HIP events around every trunk / FC launch (az_set_profiling); lanes then play one after another
     bool use_graph = true;         // AZ_GRAPH=0: launch kernel by kernel
+    bool compact = true;           // AZ_COMPACT=0: never move the active slots to the front between plies (k_refill)
     TapeProducer *tapes = nullptr; // running while a self-play episode with engine-generated tapes is open
     bool stream_tapes = true;      // AZ_TAPE_STREAM=0: generate every tape before the first ply
     int tape_threads = 4;          // AZ_TAPE_THREADS: host threads of the tape producer
@@ -632,6 +634,8 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
     e->profile = pe && pe[0] == '1';
     const char *pz = getenv("AZ_PERSIST");
     e->persist_allowed = !(pz && pz[0] == '0');
+    const char *cz = getenv("AZ_COMPACT");
+    e->compact = !(cz && cz[0] == '0');
     const char *ge = getenv("AZ_GRAPH");
     e->use_graph = !(ge && ge[0] == '0');
     const char *ts = getenv("AZ_TAPE_STREAM");
@@ -881,18 +885,19 @@ static int episode_begin(az_engine *e, const EpisodeSpec &sp)
     const int K = (int)e->lanes.size();
     const int share = (sp.num_games + K - 1) / K;
     for (Lane &L : e->lanes) {
-        L.active = 0; L.plies_played = 0; L.steps = L.trunk_launches = L.plies = 0;
+        L.active = 0; L.cur = L.d.B; L.plies_played = 0; L.steps = L.trunk_launches = L.plies = 0;
         L.trunk_ms = L.nn_ms = L.step_ms = 0.0; L.rc = AZ_OK; L.err.clear();
         HIPCHECK(e, hipMemsetAsync(L.cnt.p, 0, L.cnt.bytes, L.stream));
         HIPCHECK(e, hipMemsetAsync(L.carried.p, 0xFF, L.carried.bytes, L.stream));      // -1: every slot starts from a fresh root
         if (!sp.preset) {
             HIPCHECK(e, hipMemsetAsync(L.s_status.p, 0, L.s_status.bytes, L.stream));
-            hipLaunchKernelGGL(k_refill, dim3(1), dim3(1024), 0, L.stream, L.d, share);
+            hipLaunchKernelGGL(k_refill, dim3(1), dim3(1024), 0, L.stream, L.d, share, e->compact ? 1 : 0);
             HIPCHECK(e, hipMemcpyAsync(&L.active, L.active_dev.p, 4, hipMemcpyDeviceToHost, L.stream));
         } else if (L.index != 0) {
             HIPCHECK(e, hipMemsetAsync(L.s_status.p, 0, L.s_status.bytes, L.stream));
         }
         HIPCHECK(e, hipStreamSynchronize(L.stream));
+        if (!sp.preset && e->compact && !e->reuse) L.cur = L.active;       // the active slots are the first L.active ones
     }
     if (sp.preset) e->lanes[0].active = 1;
     r.open = true;
@@ -963,9 +968,8 @@ static int ply_graph(az_engine *e, Lane &L, const LaunchCtx &lc, bool use_split,
 // runs on the lane's own host thread
 static int lane_plies(az_engine *e, Lane &L, int max_steps)
 {
-    DevState &d = L.d;
     const az_engine::Run &r = e->run;
-    const int S = d.S;
+    const int S = L.d.S;
     const bool net = e->cfg.eval_kind == AZ_EVAL_NET;
     const bool prof = net && r.profile && e->profile;
     const int nbat = ply_batches(e);
@@ -976,11 +980,17 @@ static int lane_plies(az_engine *e, Lane &L, int max_steps)
         L.ev.push_back(ev);
     }
     const int nnets = r.arena ? 2 : 1;
-    const LaunchCtx lc = ctx_of_impl(e, L);
+    const LaunchCtx lc_full = ctx_of_impl(e, L);
     // timing-only diagnostics (results are wrong): AZ_DIAG_SKIP=fc | step | fcstep
     const char *skip = getenv("AZ_DIAG_SKIP");
     const bool skip_fc = skip && strstr(skip, "fc"), skip_step = skip && strstr(skip, "step");
     for (int step = 0; step < max_steps && L.active > 0; step++) {
+        // this ply runs over the first L.cur slots: all of them, or -- after a compacting refill -- exactly the active ones
+        LaunchCtx lc = lc_full;
+        lc.d.B = L.cur;
+        lc.dv.B = L.cur * L.d.L;
+        const DevState &d = lc.d;
+        const bool full = L.cur == L.d.B;          // the captured graph holds the full grid; a shrunken ply is launched kernel by kernel
         // few pending boards: latency path (the emulated trunk has one kernel, so that its results never depend on the slot count)
         const bool use_split = e->split_max > 0 && L.scratch.p && L.active * e->vl <= e->split_max && e->trunk_mode == AZ_TRUNK_F32;
         if (e->tapes) {       // the tapes of this ply must be on the device (streamed a wave ahead of the games)
@@ -989,7 +999,7 @@ static int lane_plies(az_engine *e, Lane &L, int max_steps)
             if (trc != hipSuccess) return lane_fail(L, AZ_ERR_HIP, "tape producer: %s", hipGetErrorString(trc));
             if (ev) HIPCHECK_L(L, hipStreamWaitEvent(L.stream, ev, 0));
         }
-        if (e->use_graph && !prof && !skip) {
+        if (e->use_graph && !prof && !skip && full) {
             hipGraphExec_t exec = nullptr;
             int rcg = ply_graph(e, L, lc, use_split, nnets, net, &exec);
             if (rcg) return rcg;
@@ -1032,7 +1042,7 @@ static int lane_plies(az_engine *e, Lane &L, int max_steps)
         if (r.preset) {
             L.active = 0;
         } else {
-            hipLaunchKernelGGL(k_refill, dim3(1), dim3(1024), 0, L.stream, d, 1 << 30);
+            hipLaunchKernelGGL(k_refill, dim3(1), dim3(1024), 0, L.stream, d, 1 << 30, e->compact ? 1 : 0);
             HIPCHECK_L(L, hipMemcpyAsync(&L.active, L.active_dev.p, 4, hipMemcpyDeviceToHost, L.stream));
         }
         if (e->tapes)         // finished games need no further tape (g_nply only ever goes from 0 to the game's length, so
@@ -1040,6 +1050,7 @@ static int lane_plies(az_engine *e, Lane &L, int max_steps)
             HIPCHECK_L(L, hipMemcpyAsync(e->tapes->h_done, e->g_nply.p, (size_t)r.num_games * 4, hipMemcpyDeviceToHost, L.stream));
         HIPCHECK_L(L, hipStreamSynchronize(L.stream));
         HIPCHECK_L(L, hipGetLastError());
+        if (!r.preset && e->compact && !e->reuse && L.active > 0) L.cur = L.active;
         L.plies_played++;
         if (prof) {
             for (int i = 0; i < (e->persist_gp ? 1 : nbat); i++) {
