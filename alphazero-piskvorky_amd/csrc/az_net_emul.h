@@ -220,16 +220,16 @@ __device__ __forceinline__ void emul_sched_tiles()
     }
 }
 
-enum { BF3_OUT_IMAGE = 0, BF3_OUT_HEADS = 1,      // where the result goes
-       BF3_SKIP = 2,                                // relu(acc + bias + keep[tile]): the residual block's skip connection, from registers
-       BF3_KEEP = 4 };                              // keep[tile] = the layer's output (float32), the next block's skip operand
+enum { EMUL_OUT_IMAGE = 0, EMUL_OUT_HEADS = 1,      // where the result goes
+       EMUL_SKIP = 2,                                // relu(acc + bias + keep[tile]): the residual block's skip connection, from registers
+       EMUL_KEEP = 4 };                              // keep[tile] = the layer's output (float32), the next block's skip operand
 
 // One 3x3 conv layer, D[co][cell] = sum_k W[co][k] X[k][cell], k = tap * CIN + ci, on the 16-bit MFMA with both operands
 // split into NS parts.  A wave owns one channel tile x MTW cell tiles; per K-block of 32 (one tap, 32 channels) and cell tile
 // it reads NS activation fragments from LDS (a tile ahead) and issues NP MFMAs; the weight fragments of the next K-block
 // are requested from L2 before the block's MFMAs (w0 = the first block's, requested by the caller a layer ahead).
-// MODE BF3_OUT_IMAGE: barrier, relu(acc + bias) split into the COUT-channel image at out.
-// MODE BF3_OUT_HEADS (conv3, every wave owns all cell tiles): the 1x1 head convs (net.py:64,69) straight from the
+// MODE EMUL_OUT_IMAGE: barrier, relu(acc + bias) split into the COUT-channel image at out.
+// MODE EMUL_OUT_HEADS (conv3, every wave owns all cell tiles): the 1x1 head convs (net.py:64,69) straight from the
 // accumulators -- a 16-channel x 16-cell result tile is, lane for lane, the B operand of the 16x16x16 MFMA
 // (k = 4 (lane >> 4) + register), so each wave multiplies its channel tile with its 16 columns of the head weights
 // (hw: [tile][part][lane][4 x 16 bit], rows = the NH head channels) and leaves partial sums [channel tile][head][cell] at out
@@ -303,12 +303,12 @@ __device__ __forceinline__ void conv_layer_emul(const uint4 *in, void *out, cons
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
             float x = E::fold(acc[0][i][rg], acc[E::NACC - 1][i][rg]) + bco[rg];
-            if constexpr ((MODE & BF3_SKIP) != 0) x = x + keep[i][rg];
+            if constexpr ((MODE & EMUL_SKIP) != 0) x = x + keep[i][rg];
             v[i][rg] = x > 0.0f ? x : 0.0f;
         }
-        if constexpr ((MODE & BF3_KEEP) != 0) keep[i] = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
+        if constexpr ((MODE & EMUL_KEEP) != 0) keep[i] = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
     }
-    if constexpr ((MODE & BF3_OUT_HEADS) != 0) {
+    if constexpr ((MODE & EMUL_OUT_HEADS) != 0) {
         f32x4 hacc[MTW];
 #pragma unroll
         for (int i = 0; i < MTW; i++) {
@@ -451,11 +451,11 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk_emul(DevState d, NetWeight
     __syncthreads();
     for (int i = tid; i < G::CS; i += NTH) inP[i] = uint2{0u, 0u};      // the input image's bytes are part of conv2's output image
     AZ_STAMP(2);
-    conv_layer_emul<G, 32, 64, BF3_OUT_IMAGE, 6, SCH>(reinterpret_cast<const uint4 *>(lds), lds, c2x, w2, pre.b2, pre.hw, wpos, cellof, wave, lane);
+    conv_layer_emul<G, 32, 64, EMUL_OUT_IMAGE, 6, SCH>(reinterpret_cast<const uint4 *>(lds), lds, c2x, w2, pre.b2, pre.hw, wpos, cellof, wave, lane);
     __syncthreads();
     AZ_STAMP(3);
     // conv3 with the 1x1 head convs fused into its epilogue: partial sums [wave][head channel][cell] in LDS, added up here
-    conv_layer_emul<G, 64, 128, BF3_OUT_HEADS, 6, SCH>(reinterpret_cast<const uint4 *>(lds), lds, c3x, w3, pre.b3, pre.hw, wpos, cellof, wave, lane);
+    conv_layer_emul<G, 64, 128, EMUL_OUT_HEADS, 6, SCH>(reinterpret_cast<const uint4 *>(lds), lds, c3x, w3, pre.b3, pre.hw, wpos, cellof, wave, lane);
     __syncthreads();
     AZ_STAMP(4);
     for (int o = tid; o < 6 * G::MR; o += NTH) {
@@ -484,14 +484,14 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk_emul(DevState d, NetWeight
 // float32 registers (`keep`) from the epilogue that produced them to the epilogue that adds them (relu(conv2(h) + b + x)).
 // First K-block fragments and biases of layer l + 1 are requested before layer l runs.
 // ------------------------------------------------------------------------------------------------
-#ifndef AZ_RES_BF3_NW
-#define AZ_RES_BF3_NW 8       // waves per workgroup of the emulated ResidualBlock trunk (0 = as k_trunk_res: 12 at n = 15).  Measured at n = 15:
+#ifndef AZ_RES_EMUL_NW
+#define AZ_RES_EMUL_NW 8       // waves per workgroup of the emulated ResidualBlock trunk (0 = as k_trunk_res: 12 at n = 15).  Measured at n = 15:
                               // 8 waves (4 channel tiles x 2 cell groups of 8 / 7 tiles, 256 VGPRs) 107.3 us per 256 boards, 12 waves (x 3 groups
                               // of 5, no surplus tile, 168 VGPRs and a 5-dword spill) 109.6 us
 #endif
 template <int N>
 struct ResGeoEmul : ResGeo<N> {
-    static constexpr int NW = AZ_RES_BF3_NW ? AZ_RES_BF3_NW : ResGeo<N>::NW;
+    static constexpr int NW = AZ_RES_EMUL_NW ? AZ_RES_EMUL_NW : ResGeo<N>::NW;
 };
 
 template <int N, int SCH>
@@ -603,18 +603,18 @@ __global__ __launch_bounds__(ResGeoEmul<N>::NW * 64) void k_trunk_res_emul(DevSt
 #pragma unroll 1
     for (int blk = 0; blk < 3; blk++) {
         advance(2 * blk);           // block conv1: h = relu(bn1(conv1(x)))
-        conv_layer_emul<G, 64, 64, BF3_OUT_IMAGE, NH, SCH>(X, lds, reinterpret_cast<const uint4 *>(blkx[2 * blk]), wcur, bcur, hw, wpos, cellof,
+        conv_layer_emul<G, 64, 64, EMUL_OUT_IMAGE, NH, SCH>(X, lds, reinterpret_cast<const uint4 *>(blkx[2 * blk]), wcur, bcur, hw, wpos, cellof,
                                                            wave, lane, keep);
         __syncthreads();
         advance(2 * blk + 1);
         if (blk < 2) {              // block conv2: relu(bn2(conv2(h)) + x); the new x stays in registers as well
-            conv_layer_emul<G, 64, 64, BF3_OUT_IMAGE | BF3_SKIP | BF3_KEEP, NH, SCH>(X, lds, reinterpret_cast<const uint4 *>(blkx[2 * blk + 1]),
+            conv_layer_emul<G, 64, 64, EMUL_OUT_IMAGE | EMUL_SKIP | EMUL_KEEP, NH, SCH>(X, lds, reinterpret_cast<const uint4 *>(blkx[2 * blk + 1]),
                                                                                      wcur, bcur, hw, wpos, cellof, wave, lane, keep);
         } else {                    // res3.conv2 + skip, then the 1x1 heads straight from the accumulators
             const uint2 *hx = reinterpret_cast<const uint2 *>(w.hdx[SCH - 1]) + (size_t)ng * NS * 64 + lane;
 #pragma unroll
             for (int s = 0; s < NS; s++) hw[s] = hx[s * 64];
-            conv_layer_emul<G, 64, 64, BF3_OUT_HEADS | BF3_SKIP, NH, SCH>(X, lds, reinterpret_cast<const uint4 *>(blkx[5]), wcur, bcur, hw, wpos,
+            conv_layer_emul<G, 64, 64, EMUL_OUT_HEADS | EMUL_SKIP, NH, SCH>(X, lds, reinterpret_cast<const uint4 *>(blkx[5]), wcur, bcur, hw, wpos,
                                                                           cellof, wave, lane, keep);
         }
         __syncthreads();

@@ -369,6 +369,44 @@ def test_lanes_inside_the_library_give_the_single_lane_episode(synthetic):
         assert np.array_equal(ref[5]["N"], srch["N"]) and ref[5]["action"] == srch["action"]
 
 
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_slot_compaction_between_plies_is_invisible(lanes, monkeypatch):
+    """k_refill moves the active slots to the front of a lane after every ply and the next ply is launched over them only
+    (AZ_COMPACT=0 keeps every game in the slot it was born in).  Records go by game id, so complete games with refills from
+    the shared queue, their outcomes and the work counters are identical either way, also with virtual-loss batching (items
+    per slot) and in the arena; and both equal the oracle."""
+    n, k, S, G = 9, 5, 20, 37
+    out = {}
+    for compact in ("1", "0"):
+        monkeypatch.setenv("AZ_COMPACT", compact)
+        e = az.Engine(n, k, S, 10, engines=lanes, synthetic=True, log_table=orc.numpy_log_table(S))
+        c = e.selfplay(G, seed0=913)
+        rec = e.records(); nply, res = e.games()
+        arena = e.arena(9, seed0=2, temperature_table=orc.arena_T_table(n * n))
+        e.set_virtual_loss(3)
+        cv = e.selfplay(G, seed0=913)
+        recv = e.records()
+        out[compact] = (rec, nply, res, c, arena, cv, recv)
+        e.close()
+    a, b = out["1"], out["0"]
+    for key in a[0]:
+        assert np.array_equal(a[0][key], b[0][key]), key
+        assert np.array_equal(a[6][key], b[6][key]), f"virtual loss: {key}"
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    for key in ("games", "plies", "records", "simulations", "expansions", "root_evals", "terminal_hits", "depth_sum"):
+        assert a[3][key] == b[3][key] and a[5][key] == b[5][key], key
+    assert np.array_equal(a[4]["actions"], b[4]["actions"]) and np.array_equal(a[4]["results"], b[4]["results"])
+    assert len(set(a[1].tolist())) > 3           # games of different lengths: slots really emptied at different plies
+    o = orc.Oracle(n, k, S, synthetic=True)
+    off = 0
+    for g in range(G):
+        noise, us = orc.selfplay_tape(913 + g, n)
+        r = o.selfplay_game(None, noise, us)
+        L = int(a[1][g])
+        assert L == r["nply"] and np.array_equal(a[0]["visits"][off:off + L], r["visits"]) and np.array_equal(a[0]["actions"][off:off + L], r["actions"])
+        off += L
+
+
 def test_auto_lanes_and_lane_limits():
     e = az.Engine(5, 4, 8, 1024, synthetic=True)
     assert e.lanes() == 1                        # small boards are launch-bound: one lane
