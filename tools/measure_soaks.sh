@@ -4,7 +4,7 @@
 set -o pipefail
 tr=${1:-f32}
 if [ "$tr" = f32 ]; then opt=""; tag=""; else opt="$tr"; tag="_$tr"; fi
-python tools/soak_parity.py 128 plain 400 gpurun_out/r02_soak_parity_plain$tag.json 15 $opt 2>&1 | tail -2
-python tools/soak_parity.py 32 resnet 800 gpurun_out/r02_soak_parity_resnet$tag.json 15 $opt 2>&1 | tail -2
-python tools/soak_parity.py 512 plain 200 gpurun_out/r02_soak_parity_9x9$tag.json 9 $opt 2>&1 | tail -2
-python tools/soak_parity.py 2048 plain 100 gpurun_out/r02_soak_parity_5x5_ckpt$tag.json 5 ckpt $opt 2>&1 | tail -2
+python tools/soak_parity.py 128 plain 400 gpurun_out/r02_soak_parity_plain$tag.json 15 $opt
+python tools/soak_parity.py 32 resnet 800 gpurun_out/r02_soak_parity_resnet$tag.json 15 $opt
+python tools/soak_parity.py 512 plain 200 gpurun_out/r02_soak_parity_9x9$tag.json 9 $opt
+python tools/soak_parity.py 2048 plain 100 gpurun_out/r02_soak_parity_5x5_ckpt$tag.json 5 ckpt $opt

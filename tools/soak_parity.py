@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Full-size parity soak (not part of the regular suite: minutes of host time): complete self-play games at the BASELINE
 configuration, engine vs the CPU oracle, every ply of every game bit for bit (boards, visit counts, pi, actions, z).
-usage: soak_parity.py [games] [model plain|resnet] [sims] [out.json|-] [board] [reuse] [ckpt] [bf16x3|f16x2]
+usage: soak_parity.py [games] [model plain|resnet] [sims] [out.json|-] [board] [reuse] [ckpt] [bf16x3|f16x2] [slots=N] [lanes=K]
 bf16x3 / f16x2 = an opt-in emulated trunk: reports how many free-running games (and plies before the first difference) stay identical
 to the exact-order oracle instead of demanding all of them."""
 import json, os, sys, time
@@ -27,7 +27,11 @@ if "ckpt" in sys.argv[6:]:
 else:
     sd = synthetic_resnet_state_dict(n) if model == "resnet" else synthetic_state_dict(n)
 slots = max(4, G // 2)                                       # fewer slots than games: refills are part of the soak
-eng = az.Engine(n, k, S, slots, log_table=orc.numpy_log_table(S), model=model)
+lanes = 0
+for a in sys.argv[6:]:
+    if a.startswith("slots="): slots = int(a[6:])
+    if a.startswith("lanes="): lanes = int(a[6:])
+eng = az.Engine(n, k, S, slots, engines=lanes, log_table=orc.numpy_log_table(S), model=model)
 eng.load_weights(sd, 0)
 eng.set_subtree_reuse(reuse)
 if emul:
@@ -52,11 +56,23 @@ def check(g):
     return g, r["nply"], int(nply[g]), r["result"], int(res[g]), bad, r["counters"]["expansions"], same
 
 t1 = time.perf_counter()
+import threading
+_stop = threading.Event()
+def _heartbeat():                                  # a long run has to keep writing (gpurun kills a silent one)
+    while not _stop.wait(60.0):
+        print(f"... oracle replaying, {time.perf_counter() - t1:.0f} s", flush=True)
+threading.Thread(target=_heartbeat, daemon=True).start()
+rows, t_print = [], time.perf_counter()
 with ThreadPoolExecutor(os.cpu_count() or 8) as pool:
-    rows = list(pool.map(check, range(G)))
+    for row in pool.map(check, range(G)):
+        rows.append(row)
+        if time.perf_counter() - t_print > 30.0:
+            print(f"... {len(rows)}/{G} games checked, {time.perf_counter() - t1:.0f} s", flush=True)
+            t_print = time.perf_counter()
+_stop.set()
 t_cpu = time.perf_counter() - t1
 fails = [r for r in rows if r[5] or r[1] != r[2] or r[3] != r[4]]
-summary = {"config": f"{n}x{n}/{k}, {S} sims, {model} net{' (trained 5x5 checkpoint)' if 'ckpt' in sys.argv[6:] else ''}, {G} complete games on {slots} slots"
+summary = {"config": f"{n}x{n}/{k}, {S} sims, {model} net{' (trained 5x5 checkpoint)' if 'ckpt' in sys.argv[6:] else ''}, {G} complete games on {slots} slots ({eng.lanes()} lanes)"
                      f"{', subtree reuse' if reuse else ''}, seeds {seed0}..", "plies": int(nply.sum()),
            "expansions_engine": int(c["expansions"]), "expansions_oracle": int(sum(r[6] for r in rows)),
            "games_bit_exact": G - len(fails), "games": G, "gpu_seconds": round(t_gpu, 2), "oracle_seconds": round(t_cpu, 1),
