@@ -71,3 +71,44 @@ def test_selfplay_games_bit_exact(n, k):
                 assert np.array_equal(rec[key][sl], r[key]), f"n={n} synthetic={synthetic} game {g}: {key}"
             off += L
         e.close()
+
+
+@pytest.mark.parametrize("n,k", SIZES)
+def test_emulated_trunks_and_leaf_symmetry_on_every_size(n, k):
+    """The opt-in modes on the sizes the dedicated tests do not visit: both emulation schemes within the tolerance of
+    tests/test_emulated_trunk_gpu.py for both nets, and random-symmetry leaf evaluation bit for bit against the oracle."""
+    o = orc.Oracle(n, k, 1)
+    boards, players, lasts = _positions(np.random.RandomState(500 + n), n, 21)
+    for model in ("plain", "resnet"):
+        sd = synthetic_state_dict(n) if model == "plain" else synthetic_resnet_state_dict(n)
+        onet = orc.Net(n, sd) if model == "plain" else orc.Net(n, resnet_tensors=fold_resnet_state_dict(sd))
+        e = az.Engine(n, k, 4, 9, model=model)
+        e.load_weights(sd, 0)
+        want = [onet.eval(o.encode(boards[i], int(players[i]), int(lasts[i]))) for i in range(len(players))]
+        for mode in ("bf16x3", "f16x2"):
+            e.set_trunk_mode(mode)
+            logits, P, v = e.net_eval(boards, players, lasts)
+            for i, (ol, oP, ov) in enumerate(want):
+                assert np.abs(logits[i] - ol).max() <= 2e-5 and np.abs(P[i] - oP).max() <= 1e-6, f"{model} {mode} n={n} board {i}"
+                assert abs(float(v[i]) - float(ov)) <= (5e-6 if model == "resnet" else 2e-6), f"{model} {mode} n={n} board {i}"
+            assert any(not np.array_equal(logits[i], want[i][0]) for i in range(len(want))), "the emulated trunk returned the canonical bits"
+        e.close()
+    S, G, cut = 24, 4, (0 if n <= 6 else 5)
+    sd = synthetic_state_dict(n)
+    e = az.Engine(n, k, S, 3, log_table=orc.numpy_log_table(S))
+    e.load_weights(sd, 0)
+    e.set_leaf_symmetry(True)
+    e.selfplay(G, seed0=700 + n, max_plies=cut)
+    rec = e.records(); nply, _ = e.games()
+    ol = orc.Oracle(n, k, S, leaf_sym=True)
+    onet = orc.Net(n, sd)
+    off = 0
+    for g in range(G):
+        noise, us = orc.selfplay_tape(700 + n + g, n, maxply=cut or None)
+        r = ol.selfplay_game(onet, noise, us, maxply=cut or None, game=g)
+        L = int(nply[g]); sl = slice(off, off + L)
+        assert L == r["nply"]
+        for key in ("actions", "visits", "pis"):
+            assert np.array_equal(rec[key][sl], r[key]), f"leaf symmetry n={n} game {g}: {key}"
+        off += L
+    e.close()
