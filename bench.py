@@ -8,8 +8,9 @@
 A "step" is one ply of every concurrent game on the GPU: MCTS.run (mcts.py:101-183) for each of the
 `slots` games = 1 root evaluation + `sims` simulations, i.e. (sims + 1) lock-step batches of
 {tree kernel, conv-trunk kernel, FC kernel}.  Inputs (weights, RNG tapes) are resident in HBM before
-the timed region.  After the K timed steps the same episode is played to its end (timed separately)
-so that self-play games/s is a measured number, and the episode-end record exchange is timed.
+the timed region.  After the K timed steps the same games are played as ONE whole episode in one az_selfplay call
+(timed separately) so that self-play games/s is a measured number, then a steady-state episode (games >> slots), and the
+episode-end record exchange is timed.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -175,13 +176,14 @@ def main():
         td.all_reduce(sums, op=td.ReduceOp.SUM)
     exp_all, sims_all, plies_all, depth_all, term_all = [float(x) for x in sums.tolist()]
 
-    # ---- play the episode to its end: measured games/s, then the episode-end record exchange ----
+    # ---- one whole episode: measured games/s, then the episode-end record exchange ----
+    # The instrumented episode above (warm-up, calibration ply with serialised lanes and HIP events, K timed plies) is put
+    # aside and the SAME games (same seeds) are played again in one uninstrumented az_selfplay call -- what
+    # SelfPlayManager.generate_self_play(B) costs.
     episode = None
+    eng.selfplay_end()
     if not a.no_episode:
-        te0 = time.perf_counter()
-        while active > 0:
-            active, _ = eng.selfplay_step(16)
-        cend = eng.selfplay_end()
+        cend = eng.selfplay(B, seed0=1_000_000 + rank * B)
         torch.cuda.synchronize()
         ep_local = cend["seconds"]
         tg0 = time.perf_counter()
@@ -195,8 +197,8 @@ def main():
             td.all_reduce(tot, op=td.ReduceOp.SUM)
         ep_s, tg_s = [float(x) for x in ep.tolist()]
         g_all, e_all, p_all = [float(x) for x in tot.tolist()]
-        episode = {"what": f"one episode of {B} games per GPU on {B} slots (BASELINE's shape): no refill, the slots of finished games idle "
-                           "until the longest game ends",
+        episode = {"what": f"one episode of {B} games per GPU on {B} slots (BASELINE's shape) in one az_selfplay call: no refill, the slots of "
+                           "finished games stay empty until the longest game ends",
                    "games": int(g_all), "seconds": ep_s, "games_per_sec": g_all / ep_s,
                    "node_expansions_per_sec": e_all / ep_s, "mean_plies_per_game": p_all / g_all,
                    "record_gather_seconds": tg_s, "records_gathered": int(sum(counts))}
@@ -214,8 +216,6 @@ def main():
                                        "games": int(tot[0].item()), "seconds": float(st.item()),
                                        "games_per_sec": float(tot[0].item() / st.item()),
                                        "node_expansions_per_sec": float(tot[1].item() / st.item())}
-    else:
-        eng.selfplay_end()
 
     persist = eng.persistent()
     if rank == 0:
