@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 PRE="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)"
 make -C oracle liboracle_asan.so
 LD_PRELOAD="$PRE" ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
-  AZ_ORACLE_LIB=$PWD/oracle/liboracle_asan.so python -m pytest tests/test_oracle_golden.py tests/test_resnet_cpu.py -x -q
+  AZ_ORACLE_LIB=$PWD/oracle/liboracle_asan.so python -m pytest tests/test_oracle_golden.py tests/test_resnet_cpu.py tests/test_leaf_symmetry_cpu.py -x -q
 g++ -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -fsanitize=address,undefined -o /tmp/libaz_rng_asan.so \
   alphazero-piskvorky_amd/csrc/az_rng.cpp -lpthread
 LD_PRELOAD="$PRE" ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 python3 - <<'PY'
