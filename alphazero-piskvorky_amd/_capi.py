@@ -29,7 +29,7 @@ EXPORTS = [
     "az_create", "az_destroy", "az_last_error", "az_load_weights", "az_load_weights_resnet", "az_net_eval", "az_search", "az_search_callback", "az_selfplay",
     "az_selfplay_begin", "az_selfplay_step", "az_selfplay_end", "az_selfplay_games", "az_selfplay_records", "az_record_bytes", "az_selfplay_pack", "az_examples_from_packed",
     "az_examples_gather", "az_arena", "az_rules_replay", "az_rng_selfplay_tape", "az_rng_uniforms", "az_set_profiling", "az_set_subtree_reuse", "az_get_counters", "az_get_lanes", "az_get_persistent", "az_set_virtual_loss", "az_set_eval_cache",
-    "az_set_trunk_mode", "az_get_trunk_mode", "az_set_leaf_symmetry",
+    "az_set_trunk_mode", "az_get_trunk_mode", "az_set_leaf_symmetry", "az_emul_split",
 ]
 
 

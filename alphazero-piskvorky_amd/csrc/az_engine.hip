@@ -1705,6 +1705,12 @@ extern "C" int az_set_trunk_mode(az_engine *e, int mode)
 
 extern "C" int az_get_trunk_mode(const az_engine *e) { return e ? e->trunk_mode : AZ_ERR_INVALID; }
 
+extern "C" int az_emul_split(int mode, float x, uint16_t *parts)
+{
+    if (!parts || (mode != AZ_TRUNK_BF16X3 && mode != AZ_TRUNK_F16X2)) return AZ_ERR_INVALID;
+    return emul_split(mode, x, parts) ? emul_parts(mode) : AZ_ERR_INVALID;
+}
+
 extern "C" int az_get_persistent(const az_engine *e) { return e ? e->persist_gp : AZ_ERR_INVALID; }
 
 // MCTS.run with the evaluator outside the engine: the policy_value_fn seam of mcts.py:87-93 for evaluators that are not

@@ -292,6 +292,10 @@ int az_set_leaf_symmetry(az_engine *e, int on);
  * is open. */
 int az_set_trunk_mode(az_engine *e, int mode);
 int az_get_trunk_mode(const az_engine *e);
+/* Host-side helper (needs no GPU, like az_rng_*): the 16-bit parts a weight is split into for `mode` -- bfloat16 hi, mid, lo
+ * (x = hi + mid + lo) or float16 hi, lo (x = hi + lo / 2048) as raw bit patterns.  Returns the number of parts written, or
+ * AZ_ERR_INVALID for an unknown mode or a value outside float16's range in AZ_TRUNK_F16X2. */
+int az_emul_split(int mode, float x, uint16_t *parts);
 
 /* HIP-event timing of every trunk / FC / tree-step launch (az_counters.trunk_seconds, nn_seconds, step_seconds);
  * off by default: four events per evaluation batch cost a few microseconds of stream time, which matters on small boards.

@@ -159,3 +159,31 @@ def test_replay_buffer_and_model_loader_file_formats(tmp_path):
     assert len(files) == 1 and files[0].startswith("model_") and files[0].endswith(".pt")
     m2 = ModelLoader(mdir, lambda: net.GomokuNet(board_size=5)).get_best_model()
     assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def test_emulated_trunk_weight_split_is_exact_enough():
+    """az_emul_split (host side of az_set_trunk_mode, no GPU needed): the parts a weight is split into reproduce it to
+    float32 precision -- bf16x3: hi + mid + lo, error <= 2^-24 |x|; f16x2: hi + lo / 2048, error <= 2^-22 |x| -- each part is
+    the round-to-nearest value of what the previous parts left over, and float16's range is enforced."""
+    import ctypes as C
+    from alphazero_piskvorky_amd import _capi
+    L = _capi.lib()
+    L.az_emul_split.argtypes = [C.c_int, C.c_float, C.POINTER(C.c_uint16)]
+    rs = np.random.RandomState(5)
+    xs = np.concatenate([rs.standard_normal(2000) * 10.0 ** rs.uniform(-6, 3, 2000), [0.0, 1.0, -1.0, 65503.0, 1e-30, 3.0e38]]).astype(np.float32)
+    parts = (C.c_uint16 * 3)()
+    for x in xs:
+        x = np.float32(x)
+        assert L.az_emul_split(_capi.AZ_TRUNK_BF16X3, float(x), parts) == 3
+        hi, mid, lo = [np.array([int(parts[i]) << 16], np.uint32).view(np.float32)[0] for i in range(3)]
+        assert abs(np.float64(hi) + np.float64(mid) + np.float64(lo) - np.float64(x)) <= 2.0 ** -24 * abs(np.float64(x)) + 1e-45
+        want_hi = (np.array([x]).view(np.uint32) + 0x7FFF + ((np.array([x]).view(np.uint32) >> 16) & 1)) >> 16
+        assert int(parts[0]) == int(want_hi[0])                      # round to nearest even
+        if abs(x) < 65504.0:
+            assert L.az_emul_split(_capi.AZ_TRUNK_F16X2, float(x), parts) == 2
+            h, l = [np.array([int(parts[i])], np.uint16).view(np.float16)[0] for i in range(2)]
+            assert h == np.float16(x)
+            assert abs(np.float64(h) + np.float64(l) / 2048.0 - np.float64(x)) <= 2.0 ** -22 * abs(np.float64(x)) + 2.0 ** -36
+        else:
+            assert L.az_emul_split(_capi.AZ_TRUNK_F16X2, float(x), parts) == -1       # AZ_ERR_INVALID: outside float16's range
+    assert L.az_emul_split(7, 1.0, parts) < 0
