@@ -56,7 +56,8 @@ class az_counters(C.Structure):
                 ("depth_sum", C.c_int64), ("steps", C.c_int64), ("seconds", C.c_double), ("nn_seconds", C.c_double),
                 ("trunk_seconds", C.c_double), ("trunk_launches", C.c_int64), ("trunk_boards", C.c_int64),
                 ("step_seconds", C.c_double), ("duplicate_leaves", C.c_int64), ("cache_lookups", C.c_int64),
-                ("cache_hits", C.c_int64)]
+                ("cache_hits", C.c_int64), ("tape_wait_seconds", C.c_double), ("tape_threads", C.c_int64),
+                ("host_cpus", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

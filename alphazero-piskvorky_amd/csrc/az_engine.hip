@@ -2,6 +2,7 @@
 // MFMA fragment order, the lock-step episode loop (root eval -> S x {net, expand/backup/select} -> move),
 // record export.  gfx950 only; there is no CPU implementation of the path in this library.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <atomic>
 #include <chrono>
@@ -36,6 +37,11 @@ struct PackedNet {
     DevBuf c1x[2], c2x[2], c3x[2], hdx[2];     // the convs (c1x: conv1 / stem) and head convs split into 16-bit MFMA fragments (az_net_emul.h): [0] bf16x3, [1] f16x2
     DevBuf rblkx[2][6];                // ... and the six 64 -> 64 convs of the ResidualBlock variant
     bool f16_ok = true;                // every weight of the emulated layers is inside float16's range (AZ_TRUNK_F16X2)
+    // The split fragments are packed and uploaded when a scheme is first used (az_set_trunk_mode, or az_load_weights* while
+    // a scheme is selected), not on every weight load: the training loop reloads weights every episode and mostly stays on
+    // the float32 trunk.  Until then the float32 weights of the emulated layers wait here.
+    bool emul_ready[2] = {false, false};
+    std::vector<float> hw_first, hw_conv[6], hw_pol, hw_val;
     NetWeights w{};
     ResWeights rw{};
 };
@@ -63,6 +69,7 @@ struct Lane {
     int plies_played = 0;          // plies this lane has played in the open episode
     int64_t steps = 0, trunk_launches = 0, plies = 0;
     double trunk_ms = 0.0, nn_ms = 0.0, step_ms = 0.0;
+    double tape_wait_s = 0.0;      // host time this lane's thread was blocked on a tape wave (production or its upload)
     int rc = AZ_OK;                // result of the last threaded call on this lane
     std::string err;
 };
@@ -107,6 +114,7 @@ struct az_engine {
     TapeProducer *tapes = nullptr; // running while a self-play episode with engine-generated tapes is open
     bool stream_tapes = true;      // AZ_TAPE_STREAM=0: generate every tape before the first ply
     int tape_threads = 4;          // AZ_TAPE_THREADS: host threads of the tape producer
+    int host_cpus = 1;             // CPUs this process may run on (affinity mask and cgroup quota), what the thread counts are sized from
 };
 
 static void stop_tapes(az_engine *e)
@@ -491,6 +499,36 @@ static int auto_lanes(int n, int slots)
     return k < 1 ? 1 : (k > 4 ? 4 : k);
 }
 
+// CPUs this process may run on: the affinity mask, capped by the cgroup CPU quota (v2 cpu.max, v1 cpu.cfs_quota_us);
+// std::thread::hardware_concurrency() knows about neither on every libstdc++
+static int usable_cpus()
+{
+    int n = 0;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    if (n <= 0) n = 1;
+    double quota = 0.0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char a[64] = {0};
+        long long period = 0;
+        if (fscanf(f, "%63s %lld", a, &period) == 2 && strcmp(a, "max") != 0 && period > 0) quota = atof(a) / (double)period;
+        fclose(f);
+    } else if (FILE *f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        long long q = -1, period = 0;
+        if (fscanf(f1, "%lld", &q) != 1) q = -1;
+        fclose(f1);
+        if (FILE *f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(f2, "%lld", &period) != 1) period = 0;
+            fclose(f2);
+        }
+        if (q > 0 && period > 0) quota = (double)q / (double)period;
+    }
+    if (quota >= 1.0 && quota < (double)n) n = (int)quota;
+    return n;
+}
+
 // every lane's DevState carries the shared pointers and scalars
 template <class F>
 static void each_state(az_engine *e, F f)
@@ -610,7 +648,7 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
         d.cnt = (unsigned long long *)L.cnt.p; d.active = (int *)L.active_dev.p;
         d.carried = (int *)L.carried.p; d.reuse = 0;
         d.v2w[0] = d.v2w[1] = d.v2b[0] = d.v2b[1] = nullptr;
-        d.cache = nullptr; d.cache_mask = 0; d.cache_gen = e->cache_gen; d.ext_eval = 0; d.leaf_sym = nullptr;
+        d.cache = nullptr; d.cache_mask = 0; d.cache_gen = e->cache_gen; d.ext_eval = 0; d.leaf_sym = nullptr; d.game_key0 = 0;
         if (!rc) rc = alloc_items(e, L, 1);
     }
     if (!rc) rc = dev_alloc(e, e->next_game, 16);
@@ -641,11 +679,16 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
     const char *ts = getenv("AZ_TAPE_STREAM");
     e->stream_tapes = !(ts && ts[0] == '0');
     {
-        // default: the host threads of this rank (hardware threads / ranks on the node, torchrun's LOCAL_WORLD_SIZE)
-        const unsigned hc = std::thread::hardware_concurrency();
+        // Tape producer threads.  What this process may use is its affinity mask and cgroup CPU quota, not the machine's
+        // hardware threads (a GPU box grants a job a share of its cores); the ranks of a node split that between them
+        // unless the launcher already pinned each rank to its own cores (then the mask is per rank and the split would
+        // count twice -- AZ_HOST_CPUS_PER_RANK=1 says so).  K lane threads drive the play streams; the rest, up to 32,
+        // produce tapes.
+        e->host_cpus = usable_cpus();
         const char *lw = getenv("LOCAL_WORLD_SIZE");
-        const int ranks = lw && atoi(lw) > 0 ? atoi(lw) : 1;
-        int t = hc ? (int)hc / (4 * ranks) * K : 2 * K;
+        const char *pr = getenv("AZ_HOST_CPUS_PER_RANK");
+        const int ranks = (pr && pr[0] == '1') ? 1 : (lw && atoi(lw) > 0 ? atoi(lw) : 1);
+        int t = e->host_cpus / ranks - K;
         const char *tt = getenv("AZ_TAPE_THREADS");
         if (tt) t = atoi(tt);
         e->tape_threads = t < 1 ? 1 : (t > 32 ? 32 : t);
@@ -690,6 +733,49 @@ extern "C" void az_destroy(az_engine *e)
     delete e;
 }
 
+// every weight of the layers the emulated trunks run is inside float16's range (the only part of the split that is checked
+// eagerly at az_load_weights*; NaN counts as outside)
+static bool in_f16_range(const PackedNet &p)
+{
+    auto ok = [](const std::vector<float> &v) {
+        for (float x : v)
+            if (!(std::fabs(x) < 65504.0f)) return false;
+        return true;
+    };
+    bool r = ok(p.hw_first) && ok(p.hw_pol) && ok(p.hw_val);
+    for (int i = 0; i < 6; i++) r = r && ok(p.hw_conv[i]);
+    return r;
+}
+
+// packs and uploads the split fragments of weight slot `slot` for `scheme` unless that has been done since the last load
+static int ensure_emul(az_engine *e, int slot, int scheme)
+{
+    PackedNet &p = e->net[slot];
+    const int si = scheme - 1;
+    if (!p.loaded || scheme == AZ_TRUNK_F32 || p.emul_ready[si]) return AZ_OK;
+    bool ok = true;
+    int rc = AZ_OK;
+    auto upx = [&](DevBuf &b, const std::vector<uint16_t> &x) { if (!rc) rc = upload(e, b, x.data(), x.size() * 2); };
+    if (e->cfg.model == AZ_MODEL_PLAIN) {
+        upx(p.c1x[si], pack_first_emul(scheme, p.hw_first.data(), 32, &ok));
+        upx(p.c2x[si], pack_conv_emul(scheme, p.hw_conv[0].data(), 64, 32, &ok));
+        upx(p.c3x[si], pack_conv_emul(scheme, p.hw_conv[1].data(), 128, 64, &ok));
+        upx(p.hdx[si], pack_heads_emul(scheme, p.hw_pol.data(), 4, p.hw_val.data(), 2, 128, &ok));
+        if (rc) return rc;
+        p.w.c1x[si] = p.c1x[si].p; p.w.c2x[si] = p.c2x[si].p; p.w.c3x[si] = p.c3x[si].p; p.w.hdx[si] = p.hdx[si].p;
+    } else {
+        upx(p.c1x[si], pack_first_emul(scheme, p.hw_first.data(), 64, &ok));
+        for (int i = 0; i < 6; i++) upx(p.rblkx[si][i], pack_conv_emul(scheme, p.hw_conv[i].data(), 64, 64, &ok));
+        upx(p.hdx[si], pack_heads_emul(scheme, p.hw_pol.data(), 2, p.hw_val.data(), 1, 64, &ok));
+        if (rc) return rc;
+        for (int i = 0; i < 6; i++) p.rw.blkx[si][i] = p.rblkx[si][i].p;
+        p.rw.hdx[si] = p.hdx[si].p;
+        p.rw.stemx[si] = p.c1x[si].p;
+    }
+    p.emul_ready[si] = true;
+    return AZ_OK;
+}
+
 extern "C" int az_load_weights(az_engine *e, int slot, const float *const *t)
 {
     if (!e || !t || slot < 0 || slot > 1) return fail(e, AZ_ERR_INVALID, "az_load_weights: bad argument");
@@ -705,18 +791,13 @@ extern "C" int az_load_weights(az_engine *e, int slot, const float *const *t)
     up(p.c1, pack_conv(t[0], 32, 4));   upraw(p.c1b, t[1], 32);
     up(p.c2, pack_conv(t[2], 64, 32));  upraw(p.c2b, t[3], 64);
     up(p.c3, pack_conv(t[4], 128, 64)); upraw(p.c3b, t[5], 128);
-    p.f16_ok = true;
-    for (int sch = AZ_TRUNK_BF16X3; sch <= AZ_TRUNK_F16X2 && !rc; sch++) {
-        bool ok = true;
-        const std::vector<uint16_t> x1 = pack_first_emul(sch, t[0], 32, &ok);
-        if (!rc) rc = upload(e, p.c1x[sch - 1], x1.data(), x1.size() * 2);
-        const std::vector<uint16_t> x2 = pack_conv_emul(sch, t[2], 64, 32, &ok), x3 = pack_conv_emul(sch, t[4], 128, 64, &ok);
-        const std::vector<uint16_t> xh = pack_heads_emul(sch, t[6], 4, t[10], 2, 128, &ok);
-        if (!rc) rc = upload(e, p.c2x[sch - 1], x2.data(), x2.size() * 2);
-        if (!rc) rc = upload(e, p.c3x[sch - 1], x3.data(), x3.size() * 2);
-        if (!rc) rc = upload(e, p.hdx[sch - 1], xh.data(), xh.size() * 2);
-        if (sch == AZ_TRUNK_F16X2) p.f16_ok = ok;
-    }
+    p.hw_first.assign(t[0], t[0] + 32 * 4 * 9);
+    p.hw_conv[0].assign(t[2], t[2] + 64 * 32 * 9);
+    p.hw_conv[1].assign(t[4], t[4] + 128 * 64 * 9);
+    p.hw_pol.assign(t[6], t[6] + 4 * 128);
+    p.hw_val.assign(t[10], t[10] + 2 * 128);
+    p.emul_ready[0] = p.emul_ready[1] = false;
+    p.f16_ok = in_f16_range(p);
     up(p.hd, pack_heads(t[6], 4, t[10], 2, 128));
     float hb[6] = {t[7][0], t[7][1], t[7][2], t[7][3], t[11][0], t[11][1]};
     upraw(p.hdb, hb, 6);
@@ -728,7 +809,6 @@ extern "C" int az_load_weights(az_engine *e, int slot, const float *const *t)
     p.w.hd = (const float *)p.hd.p; p.w.pf = (const float *)p.pf.p; p.w.vf = (const float *)p.vf.p;
     p.w.c1b = (const float *)p.c1b.p; p.w.c2b = (const float *)p.c2b.p; p.w.c3b = (const float *)p.c3b.p;
     p.w.hdb = (const float *)p.hdb.p; p.w.pfb = (const float *)p.pfb.p; p.w.vfb = (const float *)p.vfb.p;
-    for (int i = 0; i < 2; i++) { p.w.c1x[i] = p.c1x[i].p; p.w.c2x[i] = p.c2x[i].p; p.w.c3x[i] = p.c3x[i].p; p.w.hdx[i] = p.hdx[i].p; }
     e->cache_gen++;           // evaluations cached under the previous weights never match again
     each_state(e, [&](DevState &d) { d.v2w[slot] = (const float *)p.v2w.p; d.v2b[slot] = (const float *)p.v2b.p; d.cache_gen = e->cache_gen; });
     p.loaded = true;
@@ -736,7 +816,7 @@ extern "C" int az_load_weights(az_engine *e, int slot, const float *const *t)
         e->trunk_mode = AZ_TRUNK_F32;       // never run a net outside float16's range in the float16 scheme
         return fail(e, AZ_ERR_INVALID, "weights outside float16's range (|w| >= 65504): AZ_TRUNK_F16X2 switched off, the engine is back on AZ_TRUNK_F32");
     }
-    return AZ_OK;
+    return e->trunk_mode != AZ_TRUNK_F32 ? ensure_emul(e, slot, e->trunk_mode) : AZ_OK;
 }
 
 extern "C" int az_load_weights_resnet(az_engine *e, int slot, const float *const *t)
@@ -753,19 +833,12 @@ extern "C" int az_load_weights_resnet(az_engine *e, int slot, const float *const
     auto upraw = [&](DevBuf &b, const float *v, size_t cnt) { if (!rc) rc = upload(e, b, v, cnt * sizeof(float)); };
     up(p.c1, pack_conv(t[0], 64, 4)); upraw(p.c1b, t[1], 64);
     for (int i = 0; i < 6; i++) { up(p.rblk[i], pack_conv(t[2 + 2 * i], 64, 64)); upraw(p.rblkb[i], t[3 + 2 * i], 64); }
-    p.f16_ok = true;
-    for (int sch = AZ_TRUNK_BF16X3; sch <= AZ_TRUNK_F16X2 && !rc; sch++) {
-        bool ok = true;
-        const std::vector<uint16_t> x1 = pack_first_emul(sch, t[0], 64, &ok);
-        rc = upload(e, p.c1x[sch - 1], x1.data(), x1.size() * 2);
-        for (int i = 0; i < 6 && !rc; i++) {
-            const std::vector<uint16_t> x = pack_conv_emul(sch, t[2 + 2 * i], 64, 64, &ok);
-            rc = upload(e, p.rblkx[sch - 1][i], x.data(), x.size() * 2);
-        }
-        const std::vector<uint16_t> xh = pack_heads_emul(sch, t[14], 2, t[16], 1, 64, &ok);
-        if (!rc) rc = upload(e, p.hdx[sch - 1], xh.data(), xh.size() * 2);
-        if (sch == AZ_TRUNK_F16X2) p.f16_ok = ok;
-    }
+    p.hw_first.assign(t[0], t[0] + 64 * 4 * 9);
+    for (int i = 0; i < 6; i++) p.hw_conv[i].assign(t[2 + 2 * i], t[2 + 2 * i] + 64 * 64 * 9);
+    p.hw_pol.assign(t[14], t[14] + 2 * 64);
+    p.hw_val.assign(t[16], t[16] + 64);
+    p.emul_ready[0] = p.emul_ready[1] = false;
+    p.f16_ok = in_f16_range(p);
     up(p.hd, pack_heads(t[14], 2, t[16], 1, 64));
     float hb[3] = {t[15][0], t[15][1], t[17][0]};
     upraw(p.hdb, hb, 3);
@@ -776,11 +849,6 @@ extern "C" int az_load_weights_resnet(az_engine *e, int slot, const float *const
     p.rw.stem = (const float *)p.c1.p; p.rw.stemb = (const float *)p.c1b.p;
     for (int i = 0; i < 6; i++) { p.rw.blk[i] = (const float *)p.rblk[i].p; p.rw.blkb[i] = (const float *)p.rblkb[i].p; }
     p.rw.hd = (const float *)p.hd.p; p.rw.hdb = (const float *)p.hdb.p;
-    for (int sch = 0; sch < 2; sch++) {
-        for (int i = 0; i < 6; i++) p.rw.blkx[sch][i] = p.rblkx[sch][i].p;
-        p.rw.hdx[sch] = p.hdx[sch].p;
-        p.rw.stemx[sch] = p.c1x[sch].p;
-    }
     p.w = NetWeights{};
     p.w.pf = (const float *)p.pf.p; p.w.vf = (const float *)p.vf.p;
     p.w.pfb = (const float *)p.pfb.p; p.w.vfb = (const float *)p.vfb.p;
@@ -791,7 +859,7 @@ extern "C" int az_load_weights_resnet(az_engine *e, int slot, const float *const
         e->trunk_mode = AZ_TRUNK_F32;       // never run a net outside float16's range in the float16 scheme
         return fail(e, AZ_ERR_INVALID, "weights outside float16's range (|w| >= 65504): AZ_TRUNK_F16X2 switched off, the engine is back on AZ_TRUNK_F32");
     }
-    return AZ_OK;
+    return e->trunk_mode != AZ_TRUNK_F32 ? ensure_emul(e, slot, e->trunk_mode) : AZ_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -825,12 +893,12 @@ struct EpisodeSpec {
     bool add_noise = true, arena = false;
     bool preset = false;      // slot 0 of lane 0 already holds a position (az_search); skip the initial refill
     bool profile = true;      // this episode may be timed with HIP events (only when az_set_profiling is on)
+    unsigned game_key0 = 0;   // low 32 bits of seed0: the leaf-symmetry hash names game g by its seed, seed0 + g
 };
 
 static int host_threads()
 {
-    unsigned hc = std::thread::hardware_concurrency();
-    int t = hc ? (int)hc : 4;
+    int t = usable_cpus();
     const char *ev = getenv("AZ_HOST_THREADS");
     if (ev) t = atoi(ev);
     return t < 1 ? 1 : (t > 64 ? 64 : t);
@@ -862,8 +930,9 @@ static int episode_begin(az_engine *e, const EpisodeSpec &sp)
     if (net && sp.arena && !e->net[1].loaded) return fail(e, AZ_ERR_NO_WEIGHTS, "weights slot 1 (baseline) not loaded");
     each_state(e, [&](DevState &d) {
         d.max_plies = sp.max_plies; d.add_noise = sp.add_noise ? 1 : 0; d.arena = sp.arena ? 1 : 0;
-        d.total_games = sp.num_games; d.reuse = e->reuse;
+        d.total_games = sp.num_games; d.reuse = e->reuse; d.game_key0 = sp.game_key0;
         d.cache = (float *)e->cache.p; d.cache_mask = e->cache_mask; d.cache_gen = e->cache_gen;
+        d.ext_eval = 0;
     });
     // persistent search kernel: plain net or synthetic evaluator, the reference's sequential search, trees that fit into LDS
     e->persist_gp = 0;
@@ -886,7 +955,7 @@ static int episode_begin(az_engine *e, const EpisodeSpec &sp)
     const int share = (sp.num_games + K - 1) / K;
     for (Lane &L : e->lanes) {
         L.active = 0; L.cur = L.d.B; L.plies_played = 0; L.steps = L.trunk_launches = L.plies = 0;
-        L.trunk_ms = L.nn_ms = L.step_ms = 0.0; L.rc = AZ_OK; L.err.clear();
+        L.trunk_ms = L.nn_ms = L.step_ms = 0.0; L.tape_wait_s = 0.0; L.rc = AZ_OK; L.err.clear();
         HIPCHECK(e, hipMemsetAsync(L.cnt.p, 0, L.cnt.bytes, L.stream));
         HIPCHECK(e, hipMemsetAsync(L.carried.p, 0xFF, L.carried.bytes, L.stream));      // -1: every slot starts from a fresh root
         if (!sp.preset) {
@@ -995,8 +1064,13 @@ static int lane_plies(az_engine *e, Lane &L, int max_steps)
         const bool use_split = e->split_max > 0 && L.scratch.p && L.active * e->vl <= e->split_max && e->trunk_mode == AZ_TRUNK_F32;
         if (e->tapes) {       // the tapes of this ply must be on the device (streamed a wave ahead of the games)
             hipEvent_t ev = nullptr;
+            const auto tw0 = std::chrono::steady_clock::now();
             hipError_t trc = e->tapes->need(L.plies_played, &ev);
             if (trc != hipSuccess) return lane_fail(L, AZ_ERR_HIP, "tape producer: %s", hipGetErrorString(trc));
+            // a wave whose upload is still in flight would stall the play stream by the same amount: wait for it here so
+            // that the stall is counted (az_counters.tape_wait_seconds); normally the wave landed a ply or two ago
+            if (ev && hipEventQuery(ev) != hipSuccess) HIPCHECK_L(L, hipEventSynchronize(ev));
+            L.tape_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
             if (ev) HIPCHECK_L(L, hipStreamWaitEvent(L.stream, ev, 0));
         }
         if (e->use_graph && !prof && !skip && full) {
@@ -1076,19 +1150,30 @@ static int episode_plies(az_engine *e, int max_steps)
     const int K = (int)e->lanes.size();
     const bool sequential = K == 1 || (e->profile && r.profile);
     auto t0 = std::chrono::steady_clock::now();
-    if (sequential) {
+    if (max_steps == 0) {
+        // nothing to play (callers read the counters this way): no threads
+    } else if (sequential) {
         for (Lane &L : e->lanes)
             if (lane_plies(e, L, max_steps)) break;
     } else {
+        // nothing may unwind through the C ABI: a thread that cannot be created (std::system_error at a thread limit,
+        // bad_alloc) leaves its lane to the calling thread, which then plays it after its own
         std::vector<std::thread> th;
+        std::vector<int> inline_lanes;
         const int dev = e->cfg.device;
-        for (int i = 1; i < K; i++)
-            th.emplace_back([e, i, max_steps, dev]() {
-                Lane &L = e->lanes[i];
-                if (hipSetDevice(dev) != hipSuccess) { lane_fail(L, AZ_ERR_HIP, "hipSetDevice(%d) failed on a lane thread", dev); return; }
-                lane_plies(e, L, max_steps);
-            });
+        for (int i = 1; i < K; i++) {
+            try {
+                th.emplace_back([e, i, max_steps, dev]() {
+                    Lane &L = e->lanes[i];
+                    if (hipSetDevice(dev) != hipSuccess) { lane_fail(L, AZ_ERR_HIP, "hipSetDevice(%d) failed on a lane thread", dev); return; }
+                    lane_plies(e, L, max_steps);
+                });
+            } catch (...) {
+                inline_lanes.push_back(i);
+            }
+        }
         lane_plies(e, e->lanes[0], max_steps);
+        for (int i : inline_lanes) lane_plies(e, e->lanes[i], max_steps);
         for (auto &t : th) t.join();
     }
     auto t1 = std::chrono::steady_clock::now();
@@ -1111,7 +1196,7 @@ static int read_counters(az_engine *e, az_counters &c)
     c.steps = c.trunk_launches = c.plies = 0;
     c.duplicate_leaves = c.cache_lookups = c.cache_hits = 0;
     int64_t reused = 0;
-    double trunk_ms = 0.0, nn_ms = 0.0, step_ms = 0.0;
+    double trunk_ms = 0.0, nn_ms = 0.0, step_ms = 0.0, tape_wait = 0.0;
     for (Lane &L : e->lanes) {
         std::vector<unsigned long long> hc((size_t)L.d.B * CNT_STRIDE);
         HIPCHECK(e, az_memcpy(L.stream, hc.data(), L.cnt.p, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1127,7 +1212,11 @@ static int read_counters(az_engine *e, az_counters &c)
         }
         c.steps += L.steps; c.trunk_launches += L.trunk_launches; c.plies += L.plies;
         trunk_ms += L.trunk_ms; nn_ms += L.nn_ms; step_ms += L.step_ms;
+        if (L.tape_wait_s > tape_wait) tape_wait = L.tape_wait_s;
     }
+    c.tape_wait_seconds = tape_wait;
+    c.tape_threads = e->tapes || e->stream_tapes ? e->tape_threads : 0;
+    c.host_cpus = e->host_cpus;
     e->run.reused_roots = reused;
     c.trunk_seconds = trunk_ms * 1e-3;
     c.nn_seconds = nn_ms * 1e-3;
@@ -1238,6 +1327,7 @@ extern "C" int az_selfplay_begin(az_engine *e, const az_selfplay_args *a)
     }
     EpisodeSpec sp;
     sp.num_games = G; sp.max_plies = a->max_plies; sp.add_noise = true; sp.arena = false;
+    sp.game_key0 = (unsigned)a->seed0;
     return episode_begin(e, sp);
 }
 
@@ -1507,6 +1597,7 @@ extern "C" int az_arena(az_engine *e, const az_arena_args *a, az_arena_result *o
     HIPCHECK(e, az_memcpy(e->stream, e->u.p, hu.data(), hu.size() * 8, hipMemcpyHostToDevice));
     EpisodeSpec sp;
     sp.num_games = G; sp.max_plies = 0; sp.add_noise = false; sp.arena = true;
+    sp.game_key0 = (unsigned)a->seed0;
     az_counters c;
     if ((rc = run_episode(e, sp, &c))) return rc;
     int w = 0, l = 0, dr = 0;
@@ -1695,6 +1786,13 @@ extern "C" int az_set_trunk_mode(az_engine *e, int mode)
         for (int i = 0; i < 2; i++)
             if (e->net[i].loaded && !e->net[i].f16_ok)
                 return fail(e, AZ_ERR_INVALID, "az_set_trunk_mode: weight slot %d holds a value outside float16's range (|w| >= 65504): use AZ_TRUNK_BF16X3", i);
+    if (mode != AZ_TRUNK_F32) {
+        DEVICE_GUARD(e);
+        for (int i = 0; i < 2; i++) {
+            const int rc = ensure_emul(e, i, mode);
+            if (rc) return rc;
+        }
+    }
     if (mode != e->trunk_mode) {
         e->trunk_mode = mode;
         e->cache_gen++;           // cached evaluations of the other arithmetic never match again
@@ -1753,12 +1851,18 @@ extern "C" int az_search_callback(az_engine *e, const uint8_t *board, int player
     HIPCHECK(e, hipStreamSynchronize(e->stream));
     // the episode machinery is bypassed: this loop is the episode (one game, one ply), driven step by step from the host
     const bool had_cache = e->cache.p != nullptr;
-    each_state(e, [&](DevState &d) {
-        d.max_plies = 0; d.add_noise = noise ? 1 : 0; d.arena = 0; d.total_games = 1; d.reuse = 0;
-        d.cache = nullptr; d.ext_eval = 1;
-    });
     HIPCHECK(e, hipMemsetAsync(L.cnt.p, 0, L.cnt.bytes, e->stream));
     HIPCHECK(e, hipMemsetAsync(L.carried.p, 0xFF, L.carried.bytes, e->stream));
+    // from here on the lane states say "priors come from outside": put them back on EVERY way out (the guard below),
+    // or a later az_selfplay / az_arena would feed raw logits to the tree step as priors
+    each_state(e, [&](DevState &d) {
+        d.max_plies = 0; d.add_noise = noise ? 1 : 0; d.arena = 0; d.total_games = 1; d.reuse = 0; d.game_key0 = 0;
+        d.cache = nullptr; d.ext_eval = 1;
+    });
+    struct Restore {
+        az_engine *e; bool had_cache;
+        ~Restore() { each_state(e, [&](DevState &d) { d.ext_eval = 0; d.cache = had_cache ? (float *)e->cache.p : nullptr; }); }
+    } restore{e, had_cache};
     e->persist_gp = 0;
     LaunchCtx lc = ctx_of_impl(e, L);
     lc.synthetic = 0;
@@ -1800,7 +1904,6 @@ extern "C" int az_search_callback(az_engine *e, const uint8_t *board, int player
     } else {
         (void)hipStreamSynchronize(e->stream);
     }
-    each_state(e, [&](DevState &d) { d.ext_eval = 0; d.cache = had_cache ? (float *)e->cache.p : nullptr; });
     (void)hipMemsetAsync(L.s_status.p, 0, L.s_status.bytes, e->stream);
     (void)hipMemsetAsync(L.leaf_kind.p, 0, L.leaf_kind.bytes, e->stream);
     (void)hipStreamSynchronize(e->stream);

@@ -11,7 +11,8 @@
 //   AZ_TRUNK_F16X2   x = hi + lo / 2048, two float16 parts (11 + 11 mantissa bits; lo is stored scaled by 2^11 so that it never
 //                    falls into float16's subnormals); three of the four cross products, w_hi a_hi into one accumulator and
 //                    w_lo a_hi + w_hi a_lo into a second one that is folded in as acc + accx / 2048 (dropped: 2^-22 relative):
-//                    3 MFMAs per tile, a 5.3 x ceiling.  float16's range: activations are saturated at 65504 and weights must
+//                    3 MFMAs per tile, a 5.3 x ceiling.  float16's range: activations are saturated at 65504 (+inf too; a NaN
+//                    activation stays NaN and reaches the priors, as in the float32 and bf16x3 trunks) and weights must
 //                    stay below it (checked at az_load_weights) -- a net beyond that belongs to the other modes.
 // NOT the canonical fp order: results agree with the oracle within a tolerance (tests/test_emulated_trunk_gpu.py: logits 2e-5,
 // P 1e-6, value 2e-6 -- the tolerances the build already grants against the Python reference's torch numbers), not bit for
@@ -94,7 +95,7 @@ template <> struct Emul<EMUL_F16X2> {
     {
         float x[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) x[i] = v[i] < 65504.0f ? v[i] : 65504.0f;         // float16's range (inputs are post-ReLU: >= 0)
+        for (int i = 0; i < 4; i++) x[i] = v[i] > 65504.0f ? 65504.0f : v[i];         // float16's range (inputs are post-ReLU: >= 0); +inf saturates, NaN stays NaN like in the other trunks
         const unsigned h0 = pk_f16(x[0], x[1]), h1 = pk_f16(x[2], x[3]);
         const f32x2 f0 = unpk_f16(h0), f1 = unpk_f16(h1);
         // the remainder is exact in float32; scaled by 2^11 it is a normal float16 whenever it matters

@@ -80,6 +80,8 @@ struct DevState {
     int *it_status, *it_net;   // [B*L] per evaluation item, what the net kernels read as s_status / s_net (alias them when L == 1)
     int *leaf_sym;         // [B] opt-in random-symmetry leaf evaluation (az_set_leaf_symmetry): symmetry 0..7 the net sees the pending leaf in; nullptr = off
     int ext_eval;          // the pending rows were filled by an evaluator outside the engine (az_search_callback): priors and value as given
+    unsigned game_key0;    // leaf-symmetry hash key of game id 0 = low 32 bits of the episode's seed0: key(g) = game_key0 + g is the game's
+                           // seed, a GLOBAL name of the game that does not depend on which rank / slot / lane plays it
 };
 
 template <int N>
@@ -272,7 +274,7 @@ __global__ void k_begin(DevState d)
         lf[4 + i] = pl == 1 ? bd[4 + i] : bd[i];
     }
     d.leaf_last[it] = d.s_last[b];
-    if (d.leaf_sym) d.leaf_sym[it] = leaf_sym_of(d.s_game[b], d.s_ply[b], 0);
+    if (d.leaf_sym) d.leaf_sym[it] = leaf_sym_of((int)(d.game_key0 + (unsigned)d.s_game[b]), d.s_ply[b], 0);
     d.leaf_kind[it] = (d.reuse && d.carried[b] >= 0) ? LEAF_REUSE : LEAF_ROOT;
     d.depth[it] = 0;
     const int netid = d.arena ? (pl == 1 ? 0 : 1) : 0;   // evaluator.py:73-79: each side searches with its own net
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_sele
         d.leaf_last[b] = last;
         d.leaf_kind[b] = out_kind;
         d.depth[b] = depth;
-        if (d.leaf_sym) d.leaf_sym[b] = leaf_sym_of(game, ply, rootN + 1);     // this leaf is evaluation rootN + 1 of the search
+        if (d.leaf_sym) d.leaf_sym[b] = leaf_sym_of((int)(d.game_key0 + (unsigned)game), ply, rootN + 1);     // this leaf is evaluation rootN + 1 of the search
     }
 }
 

@@ -34,7 +34,7 @@ class SelfPlayManager:
         self.subtree_reuse = subtree_reuse    # opt-in search upgrade (mcts.py:17-22 TODO); off = the reference's fresh root every move
         self.eval_cache = eval_cache          # opt-in: positions kept in the device evaluation cache (mcts.py:17,22 TODO); results unchanged
         self.virtual_loss = virtual_loss      # opt-in: leaves per search and evaluation batch (mcts.py:17-22 TODO); 1 = sequential like the reference
-        self.trunk = trunk                    # opt-in: "bf16x3" = fp32-emulating conv trunk on the bf16 matrix cores (tolerance, not bit-exact)
+        self.trunk = trunk                    # opt-in: "bf16x3" / "f16x2" = fp32-emulating conv trunks on the 16-bit matrix cores (tolerance, not bit-exact)
         self.leaf_symmetry = leaf_symmetry    # opt-in: every net evaluation sees a pseudo-random dihedral symmetry of the position (README.md:61,82)
         self.gather_to = gather_to            # multi-rank: None = every rank receives all records (all-gather); r = only rank r does
         self.last_counters = None

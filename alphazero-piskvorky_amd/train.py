@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--eval-games", type=int, default=C.EVALUATION_GAMES)
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--model-dir", default=None)
-    ap.add_argument("--trunk", default="f32", choices=["f32", "bf16x3"], help="self-play conv trunk: f32 (bit-exact default) or the fp32-emulating bf16 trunk (opt-in)")
+    ap.add_argument("--trunk", default="f32", choices=["f32", "bf16x3", "f16x2"], help="self-play conv trunk: f32 (bit-exact default) or an fp32-emulating trunk on the 16-bit matrix cores (opt-in: bf16x3, or the faster f16x2 with float16's range)")
     ap.add_argument("--subtree-reuse", action="store_true", help="self-play keeps the chosen child's subtree between plies (opt-in search upgrade)")
     ap.add_argument("--device-replay", action="store_true", help="keep examples on the GPU (packed ring + on-device batch unpacking)")
     a = ap.parse_args()

@@ -3,7 +3,10 @@
 15x15 / 5-in-a-row, 400 simulations per move).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1 without a launcher's RANK in the environment: this process starts `python -m torch.distributed.run --nnodes=1
+  --nproc-per-node N ... bench.py <same arguments>` as a child BEFORE touching the GPU, relays the child's JSON line and exit
+  code (one rank per GPU, RCCL).  Launched by torch.distributed.run itself (the driver's N > 1 line) it is one of the ranks.
+  Fewer GPUs than ranks is an error unless --share is given (rehearsal: ranks share devices, gloo collectives).
 
 A "step" is one ply of every concurrent game on the GPU: MCTS.run (mcts.py:101-183) for each of the
 `slots` games = 1 root evaluation + `sims` simulations, i.e. (sims + 1) lock-step batches of
@@ -77,9 +80,54 @@ def cpu_baseline(n, k, sims, sd, budget_games):
             "seconds": dt}
 
 
+def launch_ranks(a, argv):
+    """--gpus N > 1 from a plain `python bench.py`: one child `torch.distributed.run` with N ranks.  This parent never
+    initialises the GPU (device_count() does not), relays the single JSON line and exits with the child's code."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < a.gpus and not a.share:
+        print(f"bench.py: --gpus {a.gpus} needs {a.gpus} GPUs, this node shows {ndev} "
+              "(--share lets ranks share devices with gloo collectives: a rehearsal, not a measurement)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in p.stdout:
+        if out.startswith("{") and line is None:
+            line = out
+        else:
+            sys.stderr.write(out)
+    rc = p.wait()
+    if line is not None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    elif rc == 0:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def device_name(index):
+    """PCI address of a device (which physical GPU a rank played on), without initialising anything beyond torch's props."""
+    pr = torch.cuda.get_device_properties(index)
+    try:
+        return f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+    except AttributeError:
+        return f"cuda:{index} {getattr(pr, 'uuid', '')}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--share", action="store_true", help="rehearsal on a node with fewer GPUs than ranks: ranks share devices (rank % devices) and "
+                    "the collectives run on gloo; without it fewer GPUs than ranks is an error")
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--board", type=int, default=15)
@@ -101,15 +149,26 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--pmc-run", action="store_true", help="counter-collection run: 8 sims per move so the pass stays short")
     a = ap.parse_args()
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
     # launched by torch.distributed.run (the driver's N > 1 launch line, also valid with one rank): collectives go through
     # the process group -- RCCL -- whatever the world size; plain `python bench.py` has no process group
     dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if a.gpus > 1 and not dist:
+        sys.exit(launch_ranks(a, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if dist and world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started {world} ranks", file=sys.stderr)
+        sys.exit(2)
     ndev = torch.cuda.device_count()
-    share = dist and ndev < world          # rehearsal on a box with fewer GPUs than ranks: ranks share devices, gloo collectives
+    if dist and ndev < world and not a.share:
+        if rank == 0:
+            print(f"bench.py: {world} ranks but {ndev} GPUs on this node (--share: ranks share devices, gloo collectives -- a rehearsal)", file=sys.stderr)
+        sys.exit(2)
+    share = dist and a.share and ndev < world     # rehearsal on a box with fewer GPUs than ranks: ranks share devices, gloo collectives
     local = local % max(ndev, 1)
     if dist:
         import torch.distributed as td
@@ -162,7 +221,7 @@ def main():
     t0 = time.perf_counter()
     active, c1 = eng.selfplay_step(a.steps)
     barrier()
-    dt = time.perf_counter() - t0
+    dt = dt_local = time.perf_counter() - t0
     if dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
@@ -175,6 +234,14 @@ def main():
     if dist:
         td.all_reduce(sums, op=td.ReduceOp.SUM)
     exp_all, sims_all, plies_all, depth_all, term_all = [float(x) for x in sums.tolist()]
+    # per rank: expansions/s over the rank's own clock, how long its play streams waited for RNG tapes, and where it ran
+    mine = {"rank": rank, "device": device_name(local), "node_expansions_per_sec": exp_local / dt_local,
+            "tape_wait_seconds": d["tape_wait_seconds"], "tape_threads": c1["tape_threads"], "host_cpus": c1["host_cpus"],
+            "lanes": a.engines}
+    ranks = [mine]
+    if dist:
+        ranks = [None] * world
+        td.all_gather_object(ranks, mine)
 
     # ---- one whole episode: measured games/s, then the episode-end record exchange ----
     # The instrumented episode above (warm-up, calibration ply with serialised lanes and HIP events, K timed plies) is put
@@ -190,32 +257,33 @@ def main():
         packed, counts = parallel.gather_packed_records(eng, dev, force=dist)
         torch.cuda.synchronize()
         tg = time.perf_counter() - tg0
-        ep = torch.tensor([ep_local, tg], dtype=torch.float64, device=cdev)
+        ep = torch.tensor([ep_local, tg, cend["tape_wait_seconds"]], dtype=torch.float64, device=cdev)
         tot = torch.tensor([cend["games"], cend["expansions"] + cend["plies"], cend["plies"]], dtype=torch.float64, device=cdev)
         if dist:
             td.all_reduce(ep, op=td.ReduceOp.MAX)
             td.all_reduce(tot, op=td.ReduceOp.SUM)
-        ep_s, tg_s = [float(x) for x in ep.tolist()]
+        ep_s, tg_s, tw_s = [float(x) for x in ep.tolist()]
         g_all, e_all, p_all = [float(x) for x in tot.tolist()]
         episode = {"what": f"one episode of {B} games per GPU on {B} slots (BASELINE's shape) in one az_selfplay call: no refill, the slots of "
                            "finished games stay empty until the longest game ends",
                    "games": int(g_all), "seconds": ep_s, "games_per_sec": g_all / ep_s,
                    "node_expansions_per_sec": e_all / ep_s, "mean_plies_per_game": p_all / g_all,
-                   "record_gather_seconds": tg_s, "records_gathered": int(sum(counts))}
+                   "record_gather_seconds": tg_s, "records_gathered": int(sum(counts)), "tape_wait_seconds": tw_s}
         # ---- steady state: games >> slots, every freed slot takes the next game of the engine's shared queue ----
         sg = a.steady_games if a.steady_games >= 0 else 3 * B
         if sg > 0:
             del packed
             cs = eng.selfplay(sg, seed0=2_000_000 + rank * sg)
-            st = torch.tensor([cs["seconds"]], dtype=torch.float64, device=cdev)
+            st = torch.tensor([cs["seconds"], cs["tape_wait_seconds"]], dtype=torch.float64, device=cdev)
             tot = torch.tensor([cs["games"], cs["expansions"] + cs["plies"]], dtype=torch.float64, device=cdev)
             if dist:
                 td.all_reduce(st, op=td.ReduceOp.MAX)
                 td.all_reduce(tot, op=td.ReduceOp.SUM)
             episode["steady_state"] = {"what": f"a second episode of {sg} games per GPU on the same {B} slots, freed slots refilled from the shared queue",
-                                       "games": int(tot[0].item()), "seconds": float(st.item()),
-                                       "games_per_sec": float(tot[0].item() / st.item()),
-                                       "node_expansions_per_sec": float(tot[1].item() / st.item())}
+                                       "games": int(tot[0].item()), "seconds": float(st[0].item()),
+                                       "games_per_sec": float(tot[0].item() / st[0].item()),
+                                       "node_expansions_per_sec": float(tot[1].item() / st[0].item()),
+                                       "tape_wait_seconds": float(st[1].item())}
 
     persist = eng.persistent()
     if rank == 0:
@@ -272,6 +340,8 @@ def main():
         out = {
             "metric": "mcts_node_expansions_per_sec", "value": exp_all / dt, "unit": "node-expansions/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / max(a.steps, 1),
+            "distinct_devices": len({r["device"] for r in ranks}), "ranks": ranks,
+            "tape_wait_seconds": max(r["tape_wait_seconds"] for r in ranks),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.trunk == "f32" else ("bf16x3 (float32 emulated by three-way bf16 splits, float32 accumulate; NOT the bit-exact default)" if a.trunk == "bf16x3"
                       else "f16x2 (float32 emulated by two-way float16 splits, float32 accumulate; NOT the bit-exact default)"),

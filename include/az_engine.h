@@ -157,6 +157,13 @@ typedef struct {
     double step_seconds;                /* HIP-event time inside the tree kernel k_step (select/expand/backup) */
     int64_t duplicate_leaves;           /* virtual-loss batching: simulations that met a leaf already pending in their batch */
     int64_t cache_lookups, cache_hits;  /* evaluation cache: positions looked up / found (a hit skips the net kernels)  */
+    /* Host side of the RNG tapes (mcts.py:114,177 draws, produced on the host ahead of the games): the longest time any
+       lane's driver thread was blocked because the tape wave of its next ply was not yet produced or uploaded -- 0 when the
+       producer keeps ahead of the games; a tape-bound run (many ranks on few cores) shows up here instead of looking like
+       a slow GPU.  tape_threads = producer threads of this engine, host_cpus = CPUs the process may use (affinity mask
+       and cgroup quota) that the count was sized from. */
+    double tape_wait_seconds;
+    int64_t tape_threads, host_cpus;
 } az_counters;
 
 int az_selfplay(az_engine *e, const az_selfplay_args *args, az_counters *out);
@@ -268,8 +275,9 @@ int az_set_eval_cache(az_engine *e, int64_t entries);
  * games.py:183-197).  With it every net evaluation of a search -- the root (mcts.py:109) and each expanded leaf
  * (mcts.py:137) -- shows the net one of the 8 dihedral symmetries of the position and maps the policy back: priors of a
  * board cell = softmax entry of the image cell it was moved to; the value is taken as is.  The symmetry of evaluation idx
- * (0 = root, s + 1 = simulation s) of game g at ply p is a fixed hash of (g, p, idx), so runs are reproducible and
- * independent of slots, lanes and ranks.  Visit counts differ from the reference's (its net always sees the position
+ * (0 = root, s + 1 = simulation s) of game g at ply p is a fixed hash of (low 32 bits of seed0 + g, p, idx) -- the game is
+ * named by its seed, which a rank playing the id block [lo, hi) of a larger episode passes as seed0 + lo -- so runs are
+ * reproducible and independent of slots, lanes and ranks (az_search / az_search_callback: key 0).  Visit counts differ from the reference's (its net always sees the position
  * unrotated); parity is against the oracle's restatement of this rule (orc_cfg.leaf_sym, "parity unpinned" by the
  * reference).  Lock-step pipeline only; not combinable with virtual-loss batching, subtree reuse, the evaluation cache or
  * az_search_callback.  Not allowed while an episode is open. */

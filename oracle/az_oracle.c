@@ -457,7 +457,7 @@ typedef struct {
     int leaf_sym;               /* opt-in random-symmetry leaf evaluation (include/az_engine.h, az_set_leaf_symmetry; SURVEY 8f-2's
                                    optional half, README.md:61,82): every evaluation shows the net one of the 8 dihedral symmetries
                                    of the position, chosen by a fixed hash of (game_id, ply, evaluation index); 0 = the reference */
-    int game_id;                /* ... the game's id in its episode (arena: the game index; single searches: 0) */
+    int game_id;                /* ... the game's global name: the low 32 bits of its seed, seed0 + id (single searches: 0) */
 } orc_cfg;
 
 typedef struct {

@@ -140,7 +140,7 @@ class Oracle:
         if not self.cfg.leaf_sym:
             return self.cfg
         c = _Cfg.from_buffer_copy(self.cfg)
-        c.game_id = int(game)
+        c.game_id = C.c_int32(int(game) & 0xFFFFFFFF).value      # the engine's key: low 32 bits of seed0 + game id
         return c
 
     # ---- rules ----
@@ -193,12 +193,13 @@ class Oracle:
                     counters=dict(expansions=int(counters[0]), sims=int(counters[1]), terminal_hits=int(counters[2]),
                                   depth_sum=int(counters[3]), root_evals=int(counters[4]), dup_sims=int(counters[5])))
 
-    def arena_game(self, cand, base, game_index, u_tape, T_table=None):
+    def arena_game(self, cand, base, game_index, u_tape, T_table=None, key=None):
+        """key: what the leaf-symmetry hash names the game by (the engine: its seed, seed0 + game_index); default game_index"""
         nn = self.n * self.n
         T_table = arena_T_table(nn) if T_table is None else np.ascontiguousarray(T_table, np.float64)
         actions = np.zeros(nn, np.int16); temps = np.zeros(nn, np.float64); nply = C.c_int()
         ut = np.ascontiguousarray(u_tape, np.float64)
-        r = lib().orc_arena_game(C.byref(self._cfg_for(game_index)), C.c_void_p(cand.h), C.c_void_p(base.h), int(game_index), _p(ut),
+        r = lib().orc_arena_game(C.byref(self._cfg_for(game_index if key is None else key)), C.c_void_p(cand.h), C.c_void_p(base.h), int(game_index), _p(ut),
                                  _p(T_table), _p(actions), _p(temps), C.byref(nply))
         return dict(result=r, nply=nply.value, actions=actions[:nply.value], temps=temps[:nply.value])
 

@@ -19,6 +19,7 @@ Fixture families:
   G6 arena_5x4.npz          ModelEvaluator.evaluate between two 5x5 checkpoints, per-game seeds
   G7 zlabels.json           the z truth table of alphazero/tests/tests.py:11-22
   G4-full netgame_full_{n}x{k}.npz  real-net plies at the BASELINE search sizes: 15x15/400 sims (7 plies), 9x9/200 sims (24 plies)
+  G4-complete netgame_complete_15x5.npz  ONE whole reference game at 15x15 / 400 sims (python make_golden.py complete)
 """
 import json
 import os
@@ -422,7 +423,9 @@ def worker(n, k):
 # 9x9 / 200 simulations (configs[2]) -- played by the Python reference itself.  Kept apart from worker() so that
 # re-running it leaves the other fixtures untouched:  python tests/golden/make_golden.py full
 # --------------------------------------------------------------------------
-def worker_full(n, k):
+def worker_full(n, k, complete=False):
+    """complete=True: ONE whole 15x15 / 400-simulation game of the Python reference from the empty board to its end
+    (netgame_complete_15x5.npz, about 8 minutes of one container core), a different seed from the 7-ply fixture."""
     sys.path.insert(0, REF)
     import constants
     constants.BOARD_SIZE, constants.WIN_LENGTH = n, k
@@ -458,8 +461,8 @@ def worker_full(n, k):
     mcts_mod.Node = RecNode
 
     S = {9: 200, 15: 400}[n]
-    maxply = {9: 24, 15: 7}[n]
-    seed = 1900
+    maxply = n * n if complete else {9: 24, 15: 7}[n]
+    seed = 1977 if complete else 1900
     net = GomokuNet(device="cpu")
     net.load_state_dict({kk: torch.tensor(v) for kk, v in build_weights(n).items()})
     net.eval()
@@ -487,13 +490,16 @@ def worker_full(n, k):
         r_["final"] = 255
     recs[-1]["final"] = res_code[fin]
     np.savez_compressed(
-        os.path.join(HERE, f"netgame_full_{n}x{k}.npz"), n=n, k=k, S=S, seed0=seed, maxply=maxply, weights="seeded",
+        os.path.join(HERE, f"netgame_{'complete' if complete else 'full'}_{n}x{k}.npz"), n=n, k=k, S=S, seed0=seed, maxply=maxply, weights="seeded",
         **{key: np.array([c[key] for c in recs]) for key in recs[0]})
 
 
 if __name__ == "__main__":
-    if len(sys.argv) == 4 and sys.argv[3] == "full":
-        worker_full(int(sys.argv[1]), int(sys.argv[2]))
+    if len(sys.argv) == 4 and sys.argv[3] in ("full", "complete"):
+        worker_full(int(sys.argv[1]), int(sys.argv[2]), complete=sys.argv[3] == "complete")
+    elif len(sys.argv) == 2 and sys.argv[1] == "complete":
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+        sys.exit(subprocess.call([sys.executable, os.path.abspath(__file__), "15", "5", "complete"], env=env, cwd="/tmp"))
     elif len(sys.argv) == 2 and sys.argv[1] == "full":
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(n), str(k), "full"], env=env, cwd="/tmp")

@@ -105,7 +105,7 @@ def test_emulated_trunks_and_leaf_symmetry_on_every_size(n, k):
     off = 0
     for g in range(G):
         noise, us = orc.selfplay_tape(700 + n + g, n, maxply=cut or None)
-        r = ol.selfplay_game(onet, noise, us, maxply=cut or None, game=g)
+        r = ol.selfplay_game(onet, noise, us, maxply=cut or None, game=700 + n + g)
         L = int(nply[g]); sl = slice(off, off + L)
         assert L == r["nply"]
         for key in ("actions", "visits", "pis"):

@@ -187,3 +187,34 @@ def test_emulated_trunk_weight_split_is_exact_enough():
         else:
             assert L.az_emul_split(_capi.AZ_TRUNK_F16X2, float(x), parts) == -1       # AZ_ERR_INVALID: outside float16's range
     assert L.az_emul_split(7, 1.0, parts) < 0
+
+
+def test_bench_gpus_n_refuses_to_measure_fewer_devices_than_ranks():
+    """`python bench.py --gpus N` starts N ranks itself (a child torch.distributed.run, before any GPU call); on a node with
+    fewer than N GPUs it must exit non-zero instead of printing a one-GPU line labelled N -- here: 0 GPUs, N = 2."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this node has the GPUs the launcher asks for")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode != 0 and "--share" in p.stderr and not p.stdout.strip()
+
+
+def test_counters_struct_mirrors_the_header():
+    """az_counters grew tape_wait_seconds / tape_threads / host_cpus this round: the ctypes mirror must have every field
+    of the header's struct, in order."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "az_engine.h")).read()
+    body = re.search(r"typedef struct \{((?:(?!typedef struct).)*?)\} az_counters;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            names += [x.strip() for x in decl.split(None, 1)[1].split(",")]
+    assert names == [f for f, _ in _capi.az_counters._fields_]

@@ -42,7 +42,7 @@ def test_selfplay_with_leaf_symmetry_bit_exact_vs_oracle(n, k, S, G, cut, model,
     off, differs = 0, 0
     for g in range(G):
         noise, us = orc.selfplay_tape(seed0 + g, n, maxply=cut or None)
-        r = o.selfplay_game(onet, noise, us, maxply=cut or None, game=g)
+        r = o.selfplay_game(onet, noise, us, maxply=cut or None, game=seed0 + g)      # the hash names a game by its seed
         L = int(nply[g]); sl = slice(off, off + L)
         assert L == r["nply"], f"game {g}"
         for key in ("actions", "boards", "visits", "pis"):
@@ -78,7 +78,7 @@ def test_single_search_and_arena_with_leaf_symmetry():
     a = e.arena(G, seed0=31, temperature_table=orc.arena_T_table(n * n))
     for g in range(G):
         us = np.random.RandomState(31 + g).random_sample(n * n)
-        rg = o.arena_game(oc, ob, g, us)
+        rg = o.arena_game(oc, ob, g, us, key=31 + g)
         assert int(a["nply"][g]) == rg["nply"] and int(a["results"][g]) == rg["result"]
         assert np.array_equal(a["actions"][g][:rg["nply"]], rg["actions"])
     e.close()

@@ -25,7 +25,8 @@ from alphazero_piskvorky_amd.weights import synthetic_state_dict
 m = net.GomokuNet(board_size=5)
 m.load_state_dict({k: torch.tensor(v) for k, v in synthetic_state_dict(5).items()})
 ctrl = NeuralNetworkController(m, device="cuda:0")
-data = SelfPlayManager(ctrl, "cuda:0", mcts_params={"num_simulations": 24}, concurrent_games=8, seed=2024).generate_self_play(13)
+data = SelfPlayManager(ctrl, "cuda:0", mcts_params={"num_simulations": 24}, concurrent_games=8, seed=2024,
+                       leaf_symmetry=len(sys.argv) > 3 and sys.argv[3] == "leafsym").generate_self_play(13)
 rank = td.get_rank() if world > 1 else 0
 np.savez(sys.argv[2] + f".{rank}.npz", s=np.stack([d[0].numpy() for d in data]), p=np.stack([d[1] for d in data]),
          z=np.array([d[2] for d in data]))
@@ -34,15 +35,18 @@ if world > 1:
 '''
 
 
-def test_selfplay_manager_two_ranks_equals_single_process(tmp_path):
+@pytest.mark.parametrize("option", ["plain", "leafsym"])
+def test_selfplay_manager_two_ranks_equals_single_process(tmp_path, option):
+    """option = leafsym: random-symmetry leaf evaluation hashes the game's GLOBAL name (its seed), so the second rank's
+    games -- local ids 0.. again -- draw the symmetries of the single-process games 7..12, not of games 0..5."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     single = str(tmp_path / "single")
-    subprocess.run([sys.executable, str(script), ROOT, single], check=True, env=env, timeout=300, stdout=subprocess.DEVNULL)
+    subprocess.run([sys.executable, str(script), ROOT, single, option], check=True, env=env, timeout=300, stdout=subprocess.DEVNULL)
     multi = str(tmp_path / "multi")
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                    "--master-addr", "127.0.0.1", "--master-port", "29733", str(script), ROOT, multi],
+                    "--master-addr", "127.0.0.1", "--master-port", "29733", str(script), ROOT, multi, option],
                    check=True, env=env, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     ref = np.load(single + ".0.npz")
     for rank in (0, 1):

@@ -88,3 +88,32 @@ def test_bench_under_torch_distributed_run_with_one_rank_agrees_with_plain_run()
     assert plain["episode"]["records_gathered"] == dist["episode"]["records_gathered"]
     assert plain["episode"]["mean_plies_per_game"] == dist["episode"]["mean_plies_per_game"]
     assert dist["value"] > 0 and 0.3 < dist["value"] / plain["value"] < 3.0
+
+
+def test_bench_gpus_n_launches_n_ranks_by_itself():
+    """`python bench.py --gpus N` with no launcher in the environment (the driver's N = 1 command shape with N > 1) must
+    run N ranks: it starts torch.distributed.run as a child before touching the GPU.  On this one-GPU box: refused without
+    --share (a one-GPU line must never be labelled N GPUs), and with --share a 4-rank rehearsal (ranks share the device,
+    gloo collectives; the box allows 6 GPU processes, so not the 8 the real node will run) whose line says n_gpus = 4, one
+    distinct device, per-rank rates, the tape-wait counter, and an exchange that gathered every rank's records."""
+    import torch
+    if torch.cuda.device_count() >= 4:
+        pytest.skip("a multi-GPU node: the real N-rank run is the driver's")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    args = ["--steps", "2", "--warmup", "1", "--board", "9", "--win", "5", "--sims", "24", "--slots", "128", "--steady-games", "0", "--no-cpu"]
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + args, env=env, timeout=600, capture_output=True, text=True, cwd=ROOT)
+    assert p.returncode != 0 and "--share" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    line = _bench([sys.executable, "bench.py", "--gpus", "4", "--share"] + args, env)
+    assert line["n_gpus"] == 4 and line["collectives"] == "gloo" and line["distinct_devices"] == 1
+    assert [r["rank"] for r in line["ranks"]] == [0, 1, 2, 3]
+    assert all(r["node_expansions_per_sec"] > 0 and r["tape_threads"] >= 1 and r["host_cpus"] >= 1 and r["tape_wait_seconds"] >= 0.0
+               for r in line["ranks"])
+    assert line["tape_wait_seconds"] == max(r["tape_wait_seconds"] for r in line["ranks"])
+    assert abs(sum(r["node_expansions_per_sec"] for r in line["ranks"]) / line["value"] - 1.0) < 0.5
+    ep = line["episode"]
+    assert ep["games"] == 4 * 128 and ep["records_gathered"] == round(ep["mean_plies_per_game"] * ep["games"])
+    # the same shard on one rank: per-game seeds make rank 0's block of the 4-rank episode this very episode
+    one = _bench([sys.executable, "bench.py", "--gpus", "1"] + args, env)
+    assert one["n_gpus"] == 1 and one["episode"]["games"] == 128 and one["ranks"][0]["device"] == line["ranks"][0]["device"]
