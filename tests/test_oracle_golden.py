@@ -119,7 +119,8 @@ def test_net_forward_vs_torch(n):
 
 
 NETGAMES = ["netgame_5x4", "netgame_9x5", "netgame_15x5",
-            "netgame_full_9x5", "netgame_full_15x5"]     # G4-full: 9x9 / 200 sims (24 plies), 15x15 / 400 sims (7 plies)
+            "netgame_full_9x5", "netgame_full_15x5",     # G4-full: 9x9 / 200 sims (24 plies), 15x15 / 400 sims (7 plies)
+            "netgame_complete_15x5"]                     # G4-complete: one whole reference game at 15x15 / 400 sims (46 plies)
 
 
 @pytest.mark.parametrize("fixture", NETGAMES)
@@ -172,6 +173,22 @@ def test_real_net_full_game_free_running():
             assert np.array_equal(r["z"], z["z"][sel])
             assert r["result"] == int(z["final"][sel[-1]])
     assert same == len(games)       # frozen fixture, deterministic search: every game, not all but one
+
+
+def test_complete_reference_game_15x15_free_running():
+    """G4-complete: ONE whole game of the Python reference at the headline shape (15x15, 400 simulations, seeded weights,
+    np.random.seed(1977)); the oracle, running free from the same RNG tape, plays the same 46 moves to the same result
+    with the same z labels, pi within 1e-6 and the reference's visit counts on every ply."""
+    z = load("netgame_complete_15x5.npz")
+    n, S = 15, int(z["S"])
+    o = orc.Oracle(n, 5, S)
+    net = orc.Net(n, weights_from_fixture(n, str(z["weights"])))
+    noise, us = orc.selfplay_tape(int(z["seed0"]), n)
+    r = o.selfplay_game(net, noise, us)
+    assert r["nply"] == len(z["ply"]) and np.array_equal(r["actions"], z["action"])
+    assert r["result"] == int(z["final"][-1]) and r["result"] != 0 and np.array_equal(r["z"], z["z"])
+    assert np.array_equal(r["visits"], z["N"]) and np.array_equal(r["boards"], z["board"])
+    np.testing.assert_allclose(r["pis"], z["pi"], rtol=0, atol=1e-6)
 
 
 def test_augmentation_bug_compatible():
