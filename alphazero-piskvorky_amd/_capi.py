@@ -30,7 +30,10 @@ EXPORTS = [
     "az_selfplay_begin", "az_selfplay_step", "az_selfplay_end", "az_selfplay_games", "az_selfplay_records", "az_record_bytes", "az_selfplay_pack", "az_examples_from_packed",
     "az_examples_gather", "az_arena", "az_rules_replay", "az_rng_selfplay_tape", "az_rng_uniforms", "az_set_profiling", "az_set_subtree_reuse", "az_get_counters", "az_get_lanes", "az_get_persistent", "az_set_virtual_loss", "az_set_eval_cache",
     "az_set_trunk_mode", "az_get_trunk_mode", "az_set_leaf_symmetry", "az_emul_split",
+    "az_dist_unique_id", "az_dist_init", "az_dist_rank", "az_dist_world", "az_dist_counts", "az_dist_gather_records",
+    "az_dist_allreduce_sum", "az_dist_broadcast",
 ]
+AZ_DIST_ID_BYTES = 128
 
 
 class AzError(RuntimeError):
@@ -111,6 +114,12 @@ def lib():
         L.az_record_bytes.argtypes = [C.c_void_p]
         L.az_rng_selfplay_tape.argtypes = [C.c_uint64, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
         L.az_rng_uniforms.argtypes = [C.c_uint64, C.c_int, C.c_void_p]
+        L.az_dist_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+        L.az_dist_gather_records.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.az_dist_counts.argtypes = [C.c_void_p, C.c_void_p]
+        L.az_dist_allreduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.az_dist_broadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+        L.az_dist_unique_id.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -133,6 +142,15 @@ def rng_selfplay_tape(seed, n, alpha=0.3, max_plies=0):
     if rc:
         raise AzError(f"az_rng_selfplay_tape failed ({rc})")
     return noise, u[:plies]
+
+
+def dist_unique_id():
+    """AZ_DIST_ID_BYTES bytes naming a new RCCL communicator (az_dist_unique_id): create on one rank, hand to all."""
+    buf = C.create_string_buffer(AZ_DIST_ID_BYTES)
+    rc = lib().az_dist_unique_id(buf)
+    if rc:
+        raise AzError(f"az_dist_unique_id failed ({rc}): {lib().az_last_error(None).decode()}")
+    return buf.raw
 
 
 def rng_uniforms(seed, count):
@@ -388,6 +406,37 @@ class Engine:
 
     def trunk_mode(self):
         return {AZ_TRUNK_BF16X3: "bf16x3", AZ_TRUNK_F16X2: "f16x2"}.get(int(lib().az_get_trunk_mode(self.h)), "f32")
+
+    # ---- multi-GPU exchange inside the library (RCCL on the engine's stream; include/az_engine.h az_dist_*) ----
+    def dist_init(self, unique_id, rank, world):
+        if len(unique_id) != AZ_DIST_ID_BYTES:
+            raise ValueError("unique_id must be AZ_DIST_ID_BYTES bytes (dist_unique_id())")
+        self._check(lib().az_dist_init(self.h, C.c_char_p(bytes(unique_id)), int(rank), int(world)), "az_dist_init")
+
+    def dist_rank(self):
+        return int(lib().az_dist_rank(self.h))
+
+    def dist_world(self):
+        return int(lib().az_dist_world(self.h))
+
+    def dist_counts(self):
+        c = np.zeros(self.dist_world(), np.int64)
+        self._check(lib().az_dist_counts(self.h, _p(c)), "az_dist_counts")
+        return [int(x) for x in c]
+
+    def dist_gather_records(self, dst, dev_ptr):
+        """dst = rank that receives every rank's packed records (-1: all ranks); dev_ptr = device buffer (0 where not receiving)."""
+        self._torch_sync()
+        self._check(lib().az_dist_gather_records(self.h, int(dst), C.c_void_p(dev_ptr or None)), "az_dist_gather_records")
+
+    def dist_allreduce_sum(self, values):
+        v = np.ascontiguousarray(values, np.int64).copy()
+        self._check(lib().az_dist_allreduce_sum(self.h, _p(v), len(v)), "az_dist_allreduce_sum")
+        return [int(x) for x in v]
+
+    def dist_broadcast(self, dev_ptr, nbytes, root=0):
+        self._torch_sync()
+        self._check(lib().az_dist_broadcast(self.h, C.c_void_p(dev_ptr), C.c_int64(int(nbytes)), int(root)), "az_dist_broadcast")
 
     def set_profiling(self, on):
         lib().az_set_profiling(self.h, 1 if on else 0)

@@ -2,6 +2,7 @@
 // MFMA fragment order, the lock-step episode loop (root eval -> S x {net, expand/backup/select} -> move),
 // record export.  gfx950 only; there is no CPU implementation of the path in this library.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <sched.h>
 
 #include <atomic>
@@ -84,7 +85,7 @@ struct az_engine {
     // shared by the lanes: tables, the game-id queue, the episode's tapes and records
     DevBuf T_table, log_table, sqrt_table, noise_off, next_game;
     DevBuf noise, u, rec_planes, rec_last, rec_action, rec_mover, rec_pi, rec_visits, g_nply, g_result, src_index;
-    int split_max = 32;            // use the split (low-latency) trunk when at most this many slots of a lane are active (measured crossover)
+    int split_max = 64;            // use the tile-split (low-latency) trunk when at most this many slots of a lane are active (measured: 32 / 64 / 128 -> 102.0 / 102.3 / 101.0 games per second on the 1024-game episode; the 51-game arena 3.08 / 1.64 / 1.64 s)
     int episode_games = 0;
     int64_t tape_len = 0;          // doubles per game in the noise tape
     bool have_episode = false;
@@ -111,6 +112,9 @@ struct az_engine {
     bool profile = false;          // HIP events around every trunk / FC launch (az_set_profiling); lanes then play one after another
     bool use_graph = true;         // AZ_GRAPH=0: launch kernel by kernel
     bool compact = true;           // AZ_COMPACT=0: never move the active slots to the front between plies (k_refill)
+    void *comm = nullptr;          // RCCL communicator of az_dist_init (ncclComm_t), one rank per engine
+    int dist_rank = 0, dist_world = 1;
+    DevBuf dist_buf, dist_pack;    // small device scratch of the collectives; this rank's packed records
     TapeProducer *tapes = nullptr; // running while a self-play episode with engine-generated tapes is open
     bool stream_tapes = true;      // AZ_TAPE_STREAM=0: generate every tape before the first ply
     int tape_threads = 4;          // AZ_TAPE_THREADS: host threads of the tape producer
@@ -354,9 +358,9 @@ static std::vector<float> pack_heads(const float *pw, int pc, const float *vw, i
 }
 static std::vector<float> pack_fc(const float *w, int nout, int kin)
 {
-    // torch Linear [out][in]; tile t covers outputs 16t..16t+15; k-step s covers k = 4s..4s+3
-    // weight groups are zero-padded to whole chunks of 16 (k_fc fetches a chunk ahead)
-    const int nt = (nout + 15) / 16, ks = (kin + 3) / 4, ks4 = (((ks + 3) / 4 + 15) / 16) * 16;
+    // torch Linear [out][in]; tile t covers outputs 16t..16t+15; k-step s covers k = 4s..4s+3; group = 4 k-steps = 16 inputs.
+    // Canonical order (az_net.h fc_chain_groups): 4 chains of qg groups each, zero-padded: [tile][4 qg][lane][4]
+    const int nt = (nout + 15) / 16, ks = (kin + 3) / 4, qg = (((kin + 15) / 16) + 3) / 4, ks4 = 4 * qg;
     std::vector<float> out((size_t)nt * ks4 * 64 * 4, 0.0f);
     for (int t = 0; t < nt; t++)
         for (int s = 0; s < ks; s++)
@@ -702,6 +706,8 @@ extern "C" int az_create(const az_config *cfg, az_engine **out)
     return AZ_OK;
 }
 
+static void dist_destroy(az_engine *e);
+
 extern "C" void az_destroy(az_engine *e)
 {
     if (!e) return;
@@ -709,6 +715,7 @@ extern "C" void az_destroy(az_engine *e)
     stop_tapes(e);
     for (Lane &L : e->lanes)
         if (L.stream) (void)hipStreamSynchronize(L.stream);
+    dist_destroy(e);
     for (Lane &L : e->lanes) {
         DevBuf *all[] = {&L.board, &L.s_game, &L.s_ply, &L.s_player, &L.s_last, &L.s_status, &L.s_net, &L.edges, &L.rows_used,
                          &L.path, &L.depth, &L.leaf_kind, &L.leaf, &L.leaf_last, &L.logits, &L.vhid, &L.pol_feat, &L.cnt,
@@ -1926,5 +1933,213 @@ extern "C" int az_search_callback(az_engine *e, const uint8_t *board, int player
             if (prior) prior[j] = legal ? row[j].P : 0.0f;
         }
     }
+    return AZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU: the episode-end exchange on RCCL, inside the library (include/az_engine.h az_dist_*).  librccl.so.1 is bound
+// at run time -- the copy a host framework (PyTorch) has already mapped if there is one, so that the process holds ONE
+// RCCL, else the system's -- and only the handful of entry points used here are resolved.
+// ------------------------------------------------------------------------------------------------
+namespace {
+typedef int nccl_result;                     // ncclResult_t; ncclSuccess = 0
+enum { NCCL_INT8 = 0, NCCL_UINT8 = 1, NCCL_INT64 = 4 };      // ncclDataType_t values used (rccl.h: ncclInt8 0, ncclUint8 1, ncclInt64 4)
+enum { NCCL_SUM = 0 };
+struct nccl_id { char internal[AZ_DIST_ID_BYTES]; };
+struct Rccl {
+    void *h = nullptr;
+    nccl_result (*GetUniqueId)(nccl_id *) = nullptr;
+    nccl_result (*CommInitRank)(void **, int, nccl_id, int) = nullptr;
+    nccl_result (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(nccl_result) = nullptr;
+    nccl_result (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    nccl_result (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    nccl_result (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    nccl_result (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    nccl_result (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    nccl_result (*GroupStart)() = nullptr;
+    nccl_result (*GroupEnd)() = nullptr;
+    std::string err;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+
+const Rccl *rccl_load(std::string *err)
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mutex);
+    Rccl &r = g_rccl;
+    if (r.h) return &r;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);          // the copy already in the process (PyTorch's), if any
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { *err = std::string("cannot load librccl.so.1: ") + (dlerror() ? dlerror() : "?"); return nullptr; }
+    bool ok = true;
+    auto sym = [&](const char *name) { void *p = dlsym(h, name); if (!p) { ok = false; *err = std::string("librccl.so.1 lacks ") + name; } return p; };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+    r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
+    r.Send = (decltype(r.Send))sym("ncclSend");
+    r.Recv = (decltype(r.Recv))sym("ncclRecv");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    if (!ok) return nullptr;
+    r.h = h;
+    return &r;
+}
+}  // namespace
+
+#define NCCLCHECK(e, R, call)                                                                      \
+    do {                                                                                           \
+        nccl_result _r = (call);                                                                   \
+        if (_r != 0) return fail(e, AZ_ERR_HIP, "%s failed: %s (%s:%d)", #call, (R)->GetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+
+static void dist_destroy(az_engine *e)
+{
+    if (e->comm && g_rccl.h) (void)g_rccl.CommDestroy(e->comm);
+    e->comm = nullptr;
+    e->dist_rank = 0;
+    e->dist_world = 1;
+    dev_free(e->dist_buf);
+    dev_free(e->dist_pack);
+}
+
+extern "C" int az_dist_unique_id(void *id)
+{
+    if (!id) return fail(nullptr, AZ_ERR_INVALID, "az_dist_unique_id: null argument");
+    std::string err;
+    const Rccl *R = rccl_load(&err);
+    if (!R) return fail(nullptr, AZ_ERR_HIP, "%s", err.c_str());
+    nccl_id nid;
+    nccl_result rc = R->GetUniqueId(&nid);
+    if (rc != 0) return fail(nullptr, AZ_ERR_HIP, "ncclGetUniqueId failed: %s", R->GetErrorString(rc));
+    memcpy(id, nid.internal, AZ_DIST_ID_BYTES);
+    return AZ_OK;
+}
+
+extern "C" int az_dist_init(az_engine *e, const void *id, int rank, int world)
+{
+    if (!e || !id || world < 1 || rank < 0 || rank >= world) return fail(e, AZ_ERR_INVALID, "az_dist_init: bad argument");
+    if (e->run.open) return fail(e, AZ_ERR_STATE, "az_dist_init: an episode is open");
+    std::string err;
+    const Rccl *R = rccl_load(&err);
+    if (!R) return fail(e, AZ_ERR_HIP, "%s", err.c_str());
+    DEVICE_GUARD(e);
+    dist_destroy(e);
+    nccl_id nid;
+    memcpy(nid.internal, id, AZ_DIST_ID_BYTES);
+    void *comm = nullptr;
+    NCCLCHECK(e, R, R->CommInitRank(&comm, world, nid, rank));
+    e->comm = comm;
+    e->dist_rank = rank;
+    e->dist_world = world;
+    return dev_alloc(e, e->dist_buf, (size_t)(world + 1) * 64 * sizeof(int64_t));
+}
+
+extern "C" int az_dist_rank(const az_engine *e) { return e ? e->dist_rank : AZ_ERR_INVALID; }
+extern "C" int az_dist_world(const az_engine *e) { return e ? e->dist_world : AZ_ERR_INVALID; }
+
+// records this rank contributes: the last episode's, 0 without one
+static int64_t dist_local_records(const az_engine *e)
+{
+    if (!e->have_episode) return 0;
+    int64_t n = 0;
+    for (int g = 0; g < e->episode_games; g++) n += e->h_nply[g];
+    return n;
+}
+
+static int dist_counts(az_engine *e, const Rccl *R, std::vector<int64_t> &counts)
+{
+    const int W = e->dist_world;
+    int64_t *dv = (int64_t *)e->dist_buf.p;          // [0] mine, [64 ..] everybody's
+    const int64_t mine = dist_local_records(e);
+    HIPCHECK(e, hipMemcpyAsync(dv, &mine, 8, hipMemcpyHostToDevice, e->stream));
+    NCCLCHECK(e, R, R->AllGather(dv, dv + 64, 1, NCCL_INT64, e->comm, e->stream));
+    counts.assign(W, 0);
+    HIPCHECK(e, az_memcpy(e->stream, counts.data(), dv + 64, (size_t)W * 8, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+extern "C" int az_dist_counts(az_engine *e, int64_t *counts)
+{
+    if (!e || !counts) return fail(e, AZ_ERR_INVALID, "az_dist_counts: bad argument");
+    if (!e->comm) return fail(e, AZ_ERR_STATE, "az_dist_counts: az_dist_init first");
+    DEVICE_GUARD(e);
+    std::vector<int64_t> c;
+    const int rc = dist_counts(e, &g_rccl, c);
+    if (rc) return rc;
+    memcpy(counts, c.data(), c.size() * 8);
+    return AZ_OK;
+}
+
+extern "C" int az_dist_gather_records(az_engine *e, int dst, void *packed_dev)
+{
+    if (!e || dst < -1) return fail(e, AZ_ERR_INVALID, "az_dist_gather_records: bad argument");
+    if (!e->comm) return fail(e, AZ_ERR_STATE, "az_dist_gather_records: az_dist_init first");
+    if (dst >= e->dist_world) return fail(e, AZ_ERR_INVALID, "az_dist_gather_records: rank %d of %d", dst, e->dist_world);
+    const Rccl *R = &g_rccl;
+    DEVICE_GUARD(e);
+    const int W = e->dist_world, me = e->dist_rank;
+    const bool receive = dst < 0 || dst == me;
+    if (receive && !packed_dev) return fail(e, AZ_ERR_INVALID, "az_dist_gather_records: a receiving rank needs a destination buffer");
+    std::vector<int64_t> counts;
+    int rc = dist_counts(e, R, counts);
+    if (rc) return rc;
+    const int64_t rb = record_bytes(e->nn), mine = counts[me];
+    std::vector<int64_t> off(W + 1, 0);
+    for (int r = 0; r < W; r++) off[r + 1] = off[r] + counts[r] * rb;
+    // this rank's records: straight into their place of the destination where this rank receives, else into a send buffer
+    unsigned char *out = (unsigned char *)packed_dev;
+    void *my_dev = nullptr;
+    if (mine > 0) {
+        if (receive) my_dev = out + off[me];
+        else {
+            if ((rc = dev_alloc(e, e->dist_pack, (size_t)(mine * rb), false))) return rc;
+            my_dev = e->dist_pack.p;
+        }
+        if ((rc = az_selfplay_pack(e, my_dev))) return rc;
+    }
+    if (W == 1) return AZ_OK;
+    NCCLCHECK(e, R, R->GroupStart());
+    nccl_result gr = 0;
+    if (mine > 0)
+        for (int r = 0; r < W && gr == 0; r++)
+            if (r != me && (dst < 0 || dst == r)) gr = R->Send(my_dev, (size_t)(mine * rb), NCCL_UINT8, r, e->comm, e->stream);
+    if (receive)
+        for (int r = 0; r < W && gr == 0; r++)
+            if (r != me && counts[r] > 0) gr = R->Recv(out + off[r], (size_t)(counts[r] * rb), NCCL_UINT8, r, e->comm, e->stream);
+    const nccl_result ge = R->GroupEnd();
+    if (gr != 0 || ge != 0) return fail(e, AZ_ERR_HIP, "RCCL send/recv of the records failed: %s", R->GetErrorString(gr != 0 ? gr : ge));
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    return AZ_OK;
+}
+
+extern "C" int az_dist_allreduce_sum(az_engine *e, int64_t *values, int n)
+{
+    if (!e || !values || n < 1 || n > 64) return fail(e, AZ_ERR_INVALID, "az_dist_allreduce_sum: 1..64 values");
+    if (!e->comm) return fail(e, AZ_ERR_STATE, "az_dist_allreduce_sum: az_dist_init first");
+    const Rccl *R = &g_rccl;
+    DEVICE_GUARD(e);
+    int64_t *dv = (int64_t *)e->dist_buf.p;
+    HIPCHECK(e, hipMemcpyAsync(dv, values, (size_t)n * 8, hipMemcpyHostToDevice, e->stream));
+    NCCLCHECK(e, R, R->AllReduce(dv, dv, (size_t)n, NCCL_INT64, NCCL_SUM, e->comm, e->stream));
+    HIPCHECK(e, az_memcpy(e->stream, values, dv, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+extern "C" int az_dist_broadcast(az_engine *e, void *buf_dev, int64_t bytes, int root)
+{
+    if (!e || !buf_dev || bytes < 0) return fail(e, AZ_ERR_INVALID, "az_dist_broadcast: bad argument");
+    if (!e->comm) return fail(e, AZ_ERR_STATE, "az_dist_broadcast: az_dist_init first");
+    if (root < 0 || root >= e->dist_world) return fail(e, AZ_ERR_INVALID, "az_dist_broadcast: root %d of %d", root, e->dist_world);
+    if (bytes == 0) return AZ_OK;
+    const Rccl *R = &g_rccl;
+    DEVICE_GUARD(e);
+    NCCLCHECK(e, R, R->Broadcast(buf_dev, buf_dev, (size_t)bytes, NCCL_UINT8, root, e->comm, e->stream));
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
     return AZ_OK;
 }

@@ -1,5 +1,6 @@
 // az_kernels.hip -- the size-templated kernels instantiated for ONE board size (compile with -DAZ_N=n).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "az_launch.h"
 
 #ifndef AZ_N
@@ -10,6 +11,7 @@
 
 namespace {
 constexpr int N = AZ_N;
+const bool g_tile_split = !(getenv("AZ_TILE_SPLIT") && getenv("AZ_TILE_SPLIT")[0] == '0');
 
 void trunk(const LaunchCtx &c, int net_id)
 {
@@ -53,6 +55,11 @@ void trunk_split(const LaunchCtx &c, int net_id)
     typedef NetGeo<N> G;
     const int ngroups = (c.dv.B + G::G - 1) / G::G;
     dim3 bt(G::NW * 64);
+    if (g_tile_split) {        // by cell tiles: two launches (az_net.h k_tile); AZ_TILE_SPLIT=0 keeps the channel-tile stages
+        hipLaunchKernelGGL((k_tile<N, 1>), dim3(ngroups, G::MT), bt, 0, c.stream, c.dv, c.w[net_id], net_id, c.scratch, c.feat);
+        hipLaunchKernelGGL((k_tile<N, 2>), dim3(ngroups, G::MT), bt, 0, c.stream, c.dv, c.w[net_id], net_id, c.scratch, c.feat);
+        return;
+    }
     hipLaunchKernelGGL((k_split<N, 1>), dim3(ngroups, 2), bt, 0, c.stream, c.dv, c.w[net_id], net_id, c.scratch, c.feat);
     hipLaunchKernelGGL((k_split<N, 2>), dim3(ngroups, 4), bt, 0, c.stream, c.dv, c.w[net_id], net_id, c.scratch, c.feat);
     hipLaunchKernelGGL((k_split<N, 3>), dim3(ngroups, 8), bt, 0, c.stream, c.dv, c.w[net_id], net_id, c.scratch, c.feat);
@@ -66,18 +73,33 @@ long long split_scratch_floats(int slots, int model)
     return (long long)((slots + G::G - 1) / G::G) * SplitGeo<N>::PER_GROUP;
 }
 
+template <class G>
+void fc_t(const LaunchCtx &c, int net_id, const NetWeights &w, unsigned long long *dbgfc)
+{
+    // few board rows: one tile per workgroup (the latency shape); many: eight per workgroup in four rounds of two (the
+    // throughput shape: 3 workgroups per board row at n = 15).  AZ_FC_SHAPE=1|8 forces one of them.
+    const int rows = (c.dv.B + 15) / 16;
+    static const int forced = getenv("AZ_FC_SHAPE") ? atoi(getenv("AZ_FC_SHAPE")) : 0;
+    if (forced == 1 || (forced < 8 && rows <= 4)) {
+        dim3 gf(rows, G::NTP + 4), bf(256);
+        hipLaunchKernelGGL((k_fc<G, 1, 1>), gf, bf, 0, c.stream, c.dv, w, net_id, (const float *)c.feat, dbgfc);
+    } else if (forced == 16) {      // experiment: 16 tiles per workgroup, 4 rounds of 4 (16 waves)
+        dim3 gf(rows, (G::NTP + 15) / 16 + 1), bf(1024);
+        hipLaunchKernelGGL((k_fc<G, 4, 4>), gf, bf, 0, c.stream, c.dv, w, net_id, (const float *)c.feat, dbgfc);
+    } else if (forced == 17) {      // experiment: 16 tiles per workgroup, 8 rounds of 2 (8 waves)
+        dim3 gf(rows, (G::NTP + 15) / 16 + 1), bf(512);
+        hipLaunchKernelGGL((k_fc<G, 2, 8>), gf, bf, 0, c.stream, c.dv, w, net_id, (const float *)c.feat, dbgfc);
+    } else {
+        dim3 gf(rows, (G::NTP + 7) / 8 + 1), bf(512);
+        hipLaunchKernelGGL((k_fc<G, 2, 4>), gf, bf, 0, c.stream, c.dv, w, net_id, (const float *)c.feat, dbgfc);
+    }
+}
+
 void fc(const LaunchCtx &c, int net_id)
 {
     unsigned long long *dbgfc = c.dbg ? c.dbg + (size_t)c.dv.B * 16 : nullptr;
-    if (c.model == 1) {
-        typedef ResGeo<N> G;
-        dim3 gf((c.dv.B + 15) / 16, G::NSPLIT), bf(G::FCW * 64);
-        hipLaunchKernelGGL(k_fc<G>, gf, bf, 0, c.stream, c.dv, c.w[net_id], net_id, (const float *)c.feat, dbgfc);
-    } else {
-        typedef NetGeo<N> G;
-        dim3 gf((c.dv.B + 15) / 16, G::NSPLIT), bf(G::FCW * 64);
-        hipLaunchKernelGGL(k_fc<G>, gf, bf, 0, c.stream, c.dv, c.w[net_id], net_id, (const float *)c.feat, dbgfc);
-    }
+    if (c.model == 1) fc_t<ResGeo<N>>(c, net_id, c.w[net_id], dbgfc);
+    else fc_t<NetGeo<N>>(c, net_id, c.w[net_id], dbgfc);
 }
 
 void step(const LaunchCtx &c, int rootN, int do_select)

@@ -37,6 +37,13 @@ struct NetWeights {
     const void *c1x[2], *c2x[2], *c3x[2], *hdx[2];    // the convs and head convs split into 16-bit fragments (az_net_emul.h), [0] bf16x3, [1] f16x2
 };
 
+// Canonical order of an FC output over K inputs (oracle: fc_dot): the inputs are taken in groups of 16 (four k-steps of
+// v_mfma_f32_16x16x4_f32) and cut into FOUR contiguous blocks of fc_chain_groups(K) groups; each block is one k-ordered fma
+// chain from +0, and the output is ((p0 + p1) + (p2 + p3)) + bias.  Four chains instead of one so that an output tile's
+// contraction spreads over four wavefronts (k_fc) or four independent accumulators (k_search) -- a 15x15 policy output is
+// 4 x 60 dependent MFMAs instead of 228.
+__host__ __device__ constexpr int fc_chain_groups(int K) { return (((K + 15) / 16) + 3) / 4; }
+
 __host__ __device__ constexpr int up16(int x) { return x + ((16 - (x % 32) + 32) % 32); }   // smallest y >= x, y == 16 (mod 32)
 
 // Boards per trunk workgroup for an n x n board: as many as fit the LDS budget, at most 4 (so that 1024 games still
@@ -78,16 +85,14 @@ struct NetGeo {
     // FC kernel
     static constexpr int PC = 4, VC = 2;                           // policy_conv / value_conv output channels (net.py:46,52)
     static constexpr int NTP = (nn + 15) / 16;                     // policy N-tiles
-    static constexpr int KSP = (PC * nn + 3) / 4;                  // policy k-steps
-    static constexpr int KSV = (VC * nn + 3) / 4;                  // value_fc1 k-steps
     static constexpr int FROW = (((PC + VC) * nn + 3) / 4) * 4;    // feature row in HBM: [0,PC*nn) policy, [PC*nn,(PC+VC)*nn) value, zero tail
-    static constexpr int KS4P_PAD = (((KSP + 3) / 4 + 15) / 16) * 16;   // policy weight groups padded to chunks of 16
-    static constexpr int KS4V_PAD = (((KSV + 3) / 4 + 15) / 16) * 16;
-    static constexpr int FNEED = (KS4P_PAD * 16 > PC * nn + KS4V_PAD * 16) ? KS4P_PAD * 16 : PC * nn + KS4V_PAD * 16;
-    static constexpr int FSTR0 = FROW > FNEED ? FROW : FNEED;     // the padded k-steps read (zero) LDS beyond the row
+    // FC layers (fc_chains below): K inputs = groups of 16 (four MFMA k-steps), cut into 4 chains of QG groups each
+    static constexpr int QGP = fc_chain_groups(PC * nn), QGV = fc_chain_groups(VC * nn);
+    static constexpr int QGMAX = QGP > QGV ? QGP : QGV;
+        // LDS feature rows of the persistent search kernel: policy inputs, then value inputs, each padded to whole chains (zeros)
+    static constexpr int VOFFL = 64 * QGP;
+    static constexpr int FSTR0 = 64 * (QGP + QGV);
     static constexpr int FSTR = FSTR0 + ((4 - (FSTR0 % 32) + 32) % 32);   // LDS row stride, == 4 (mod 32), multiple of 4
-    static constexpr int FCW = 8;                                  // waves per k_fc workgroup (one 16x16 output tile each)
-    static constexpr int NSPLIT = (NTP + 4 + FCW - 1) / FCW;       // workgroups per 16-board row: (B/16)*NSPLIT <= 256 -> one round
 };
 
 
@@ -107,16 +112,9 @@ struct ResGeo {
     static constexpr int NW = N == 15 ? 12 : 8;                    // 4 channel tiles x {3,2} cell-tile groups: 15 = 3 x 5 tiles, no surplus
     static constexpr int PC = 2, VC = 1;
     static constexpr int NTP = (nn + 15) / 16;
-    static constexpr int KSP = (PC * nn + 3) / 4;
-    static constexpr int KSV = (VC * nn + 3) / 4;
     static constexpr int FROW = (((PC + VC) * nn + 3) / 4) * 4;
-    static constexpr int KS4P_PAD = (((KSP + 3) / 4 + 15) / 16) * 16;
-    static constexpr int KS4V_PAD = (((KSV + 3) / 4 + 15) / 16) * 16;
-    static constexpr int FNEED = (KS4P_PAD * 16 > PC * nn + KS4V_PAD * 16) ? KS4P_PAD * 16 : PC * nn + KS4V_PAD * 16;
-    static constexpr int FSTR0 = FROW > FNEED ? FROW : FNEED;
-    static constexpr int FSTR = FSTR0 + ((4 - (FSTR0 % 32) + 32) % 32);
-    static constexpr int FCW = 8;
-    static constexpr int NSPLIT = (NTP + 4 + FCW - 1) / FCW;
+    static constexpr int QGP = fc_chain_groups(PC * nn), QGV = fc_chain_groups(VC * nn);
+    static constexpr int QGMAX = QGP > QGV ? QGP : QGV;
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
@@ -144,17 +142,23 @@ enum { CONV_OUT_PACKED = 0, CONV_OUT3 = 1, CONV_OUT_RESIDUAL = 2 };   // RESIDUA
 // [co][cell] image that overlays the (now dead) inputs.
 // NTL / nt_base: the split (low-latency) kernels give one workgroup only NTL of the layer's channel tiles, starting
 // at tile nt_base; the fused kernels use all of them.
-template <class G, int CIN, int COUT, int MODE, int NTL = COUT / 16>
+// MTL / mt_base / mt_cnt: the tile-split kernels (k_tile) give one workgroup only the cell tiles mt_base .. mt_base + mt_cnt - 1
+// (mt_cnt <= MTL); GO / out_pos_off: their packed output goes to an image of another geometry (the full board image in
+// global memory) at positions shifted by out_pos_off; O3S: row stride of the [co][cell] output of CONV_OUT3, whose columns
+// are counted from the workgroup's first tile.  The fused kernels use the defaults (all tiles, same geometry).
+template <class G, int CIN, int COUT, int MODE, int NTL = COUT / 16, int MTL = G::MT, class GO = G, int O3S = G::CS3>
 __device__ __forceinline__ void conv_layer(const float *in, float *out, const float *__restrict__ wp,
                                            const float *__restrict__ bias, const unsigned short *wpos,
-                                           const unsigned short *cellof, int wave, int lane, int nt_base = 0)
+                                           const unsigned short *cellof, int wave, int lane, int nt_base = 0,
+                                           int mt_base = 0, int mt_cnt = MTL, int out_pos_off = 0)
 {
     constexpr bool OUT3 = MODE == CONV_OUT3;
+    constexpr bool SUBSET = MTL < G::MT;                       // a tile-split kernel: waves without a tile skip the layer
     constexpr int NT = NTL;                                    // channel tiles handled by this workgroup
     constexpr int NTW = (AZ_NTW <= NT) ? AZ_NTW : NT;          // channel tiles per wave
     constexpr int NG = NT / NTW;                               // channel-tile groups
     constexpr int MG = (G::NW / NG) > 0 ? (G::NW / NG) : 1;    // cell-tile groups
-    constexpr int MTW = (G::MT + MG - 1) / MG;
+    constexpr int MTW = (MTL + MG - 1) / MG;
     constexpr int KST = CIN / 4;           // k-steps per tap
     constexpr int KS = 9 * KST;
     constexpr int KS4 = (KS + 3) / 4;
@@ -176,13 +180,14 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
     for (int t = 0; t < NTW; t++)
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) bias_pre[t][rg] = bias[(nt_base + ng * NTW + t) * 16 + q * 4 + rg];
+    if (!SUBSET || mg < mt_cnt) {
     if constexpr (CIN == 4) {
         // conv1: 9 k-steps (one per tap), channels = {mover, opponent, last move, zero plane}, planes [ci][pos]
         int rb[MTW];
 #pragma unroll
         for (int i = 0; i < MTW; i++) {
             int mt = mg + i * MG;
-            int m = (mt < G::MT ? mt : 0) * 16 + r16;       // a surplus tile aliases tile 0 (computed, never written back)
+            int m = (mt_base + (mt < mt_cnt ? mt : 0)) * 16 + r16;       // a surplus tile aliases the first one (computed, never written back)
             rb[i] = (int)wpos[m] - (G::PW + 1) + q * G::CS;
         }
         float bk[NTW][12];
@@ -213,7 +218,7 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
 #pragma unroll
         for (int i = 0; i < MTW; i++) {
             int mt = mg + i * MG;
-            int m = (mt < G::MT ? mt : 0) * 16 + r16;
+            int m = (mt_base + (mt < mt_cnt ? mt : 0)) * 16 + r16;
             ra[i] = (int)wpos[m] - (G::PW + 1) + q * G::CS;
         }
         float4 a0[MTW], a1[MTW];
@@ -262,6 +267,7 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
                 for (int j = 0; j < NQ; j++) bw[t][j] = bnx[t][j];
         }
     }
+    }
     if constexpr (OUT3) __syncthreads();   // every wave has finished reading the conv3 input image
 #pragma unroll
     for (int t = 0; t < NTW; t++) {
@@ -272,23 +278,23 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
 #pragma unroll
         for (int i = 0; i < MTW; i++) {
             const int mt = mg + i * MG;
-            if (mt < G::MT) {
-                const int m = mt * 16 + r16;
+            if (mt < mt_cnt) {
+                const int m = (mt_base + mt) * 16 + r16;
                 const bool valid = cellof[m] != 0xFFFFu;
-                const int pos = wpos[m];
+                const int pos = (int)wpos[m] + out_pos_off;
 #pragma unroll
                 for (int rg = 0; rg < 4; rg++) {
                     const int co = nt * 16 + q * 4 + rg;      // = 16*cg + 4*e + q' with cg = nt, e = q, q' = rg
                     float v = acc[t][i][rg] + bco[rg];
                     v = v > 0.0f ? v : 0.0f;
-                    if constexpr (OUT3) out[co * G::CS3 + m] = v;
+                    if constexpr (OUT3) out[co * O3S + mt * 16 + r16 + (SUBSET ? 0 : mt_base * 16)] = v;
                     else if constexpr (MODE == CONV_OUT_RESIDUAL) {
                         if (valid) {                          // net block: relu(bn2(conv2(h)) + x), x updated in place
-                            const int oi = pk_index<G>(co, pos);
+                            const int oi = pk_index<GO>(co, pos);
                             float r = acc[t][i][rg] + bco[rg] + out[oi];
                             out[oi] = r > 0.0f ? r : 0.0f;
                         }
-                    } else if (valid) out[pk_index<G>(co, pos)] = v;
+                    } else if (valid) out[pk_index<GO>(co, pos)] = v;
                 }
             }
         }
@@ -609,6 +615,206 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_split(DevState d, NetWeights w, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Tile-split trunk (GomokuNet): the low-latency path, round 3.  k_split above spreads a board over workgroups by CHANNEL
+// tiles, so every layer is a launch (each needs all channels of its input), conv3 runs 2 x 144 MFMAs per wave and the
+// 1x1 heads need a fourth launch that reads the whole 123 KB conv3 image back.  Measured at one pending board
+// (profiles/r03_*): 4.6 + 9.0 + 15.2 + 8.6 us of kernels per evaluation, launch gaps ~0.3 us each -- the gaps are not the
+// cost, the kernels are.  Here a board is spread by CELL tiles (one 16-cell MFMA tile = one board row at n = 15):
+//   stage A  grid (groups, MT): encode the rows around tile t, conv1 on the <= 4 tiles conv2 needs (recomputed per
+//            workgroup: 9 k-steps), conv2 on tile t (4 waves x 72 MFMAs)        -> img2, the packed 64-channel board image
+//   stage B  grid (groups, MT): the rows of img2 around tile t -> conv3 on tile t (8 waves x 144 MFMAs: all 128 channels of
+//            the tile's cells are in THIS workgroup) -> 1x1 heads of the tile (32 MFMAs) -> feature rows
+// Two launches instead of four, no conv3 image, 16-24 KB of LDS per workgroup (several per CU).  Every output element is
+// the same k-ordered fma chain as in k_trunk -- which workgroup computes it does not enter -- so the results are
+// bit-identical (every parity test runs on this path too).
+// ------------------------------------------------------------------------------------------------
+template <int N>
+struct TileGeo {
+    typedef NetGeo<N> F;
+    static constexpr int PW = F::PW, PP = F::PP, MT = F::MT, nn = F::nn, M = F::M;
+    // padded-image position of tile lane m (the centre of its 3x3 window), -1 for a lane without a cell to compute
+    __host__ __device__ static constexpr int centre(int m)
+    {
+        if (F::ROWT) {
+            const int t = m >> 4, c = m & 15, g = t / N, r = t - g * N;
+            return g * PP + (r + 1) * PW + (c + 1);          // c == N: the row's right padding cell (computed, never stored)
+        }
+        if (m >= M) return -1;
+        const int g = m / nn, p = m - g * nn, r = p / N, c = p - r * N;
+        return g * PP + (r + 1) * PW + (c + 1);
+    }
+    __host__ __device__ static constexpr int lo_of(int t)
+    {
+        int v = 1 << 30;
+        for (int i = 0; i < 16; i++) { const int c = centre(16 * t + i); if (c >= 0 && c < v) v = c; }
+        return v;
+    }
+    __host__ __device__ static constexpr int hi_of(int t)
+    {
+        int v = -1;
+        for (int i = 0; i < 16; i++) { const int c = centre(16 * t + i); if (c > v) v = c; }
+        return v;
+    }
+    // conv1 tiles stage A computes for tile t: every tile with a cell next to a cell of t (same board group)
+    __host__ __device__ static constexpr int c1_lo(int t)
+    {
+        if (F::ROWT) return (t % N) > 0 ? t - 1 : t;
+        const int a = 16 * t - (N + 1);
+        return a < 0 ? 0 : a >> 4;
+    }
+    __host__ __device__ static constexpr int c1_hi(int t)
+    {
+        if (F::ROWT) return (t % N) < N - 1 ? t + 1 : t;
+        const int b = (16 * t + 15 + N + 1) >> 4;
+        return b > MT - 1 ? MT - 1 : b;
+    }
+    // origins (first padded-image position held in LDS) and extents of the two stages' images
+    __host__ __device__ static constexpr int org_b(int t) { return lo_of(t) - (PW + 1); }
+    __host__ __device__ static constexpr int org_a(int t) { return lo_of(c1_lo(t)) - (PW + 1); }
+    __host__ __device__ static constexpr int span_b()
+    {
+        int v = 0;
+        for (int t = 0; t < MT; t++) { const int e = hi_of(t) + (PW + 1) - org_b(t) + 1; if (e > v) v = e; }
+        return v;
+    }
+    __host__ __device__ static constexpr int span_a()
+    {
+        int v = 0;
+        for (int t = 0; t < MT; t++) { const int e = hi_of(c1_hi(t)) + (PW + 1) - org_a(t) + 1; if (e > v) v = e; }
+        return v;
+    }
+    __host__ __device__ static constexpr int c1_tiles()
+    {
+        int v = 0;
+        for (int t = 0; t < MT; t++) { const int e = c1_hi(t) - c1_lo(t) + 1; if (e > v) v = e; }
+        return v;
+    }
+    static constexpr int CSA = ((span_a() + 15) / 16) * 16, CSB = ((span_b() + 15) / 16) * 16;   // plane strides: multiples of 16 (conflict-free b128 reads)
+    static constexpr int MTL1 = c1_tiles();
+    static_assert(MTL1 <= 4, "stage A covers conv1 with 8 waves = 2 channel tiles x 4 cell tiles");
+    // what conv_layer sees of the geometry in each stage: the full board's tiling, the local image's stride
+    struct A { static constexpr int NW = F::NW, MT = F::MT, PW = F::PW, CS = CSA, CS3 = 16; };
+    struct B { static constexpr int NW = F::NW, MT = F::MT, PW = F::PW, CS = CSB, CS3 = 16; };
+    static constexpr int LDSA = 36 * CSA, LDSB = 64 * CSB + 128 * 16;
+};
+
+template <int N, int STAGE>
+__global__ __launch_bounds__(AZ_NW * 64) void k_tile(DevState d, NetWeights w, int net_id, float *__restrict__ scratch,
+                                                     float *__restrict__ feat)
+{
+    typedef NetGeo<N> F;
+    typedef TileGeo<N> TG;
+    typedef SplitGeo<N> SG;
+    constexpr int NTH = F::NW * 64;
+    __shared__ __attribute__((aligned(16))) float lds[STAGE == 1 ? TG::LDSA : TG::LDSB];
+    __shared__ unsigned short wpos[F::MR];      // centre of tile lane m RELATIVE to this workgroup's image origin
+    __shared__ unsigned short cellof[F::MR];
+    __shared__ int any_active;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = blockIdx.x, t = blockIdx.y, b0 = grp * F::G;
+    if (tid == 0) any_active = 0;
+    __syncthreads();
+    if (tid < F::G) {
+        const int b = b0 + tid;
+        if (b < d.B) {
+            const int kind = d.leaf_kind[b];
+            if ((kind == LEAF_ROOT || kind == LEAF_EXPAND) && d.s_status[b] == SLOT_ACTIVE && d.s_net[b] == net_id)
+                atomicOr(&any_active, 1);
+        }
+    }
+    const int org = STAGE == 1 ? TG::org_a(t) : TG::org_b(t);
+    constexpr int CSL = STAGE == 1 ? TG::CSA : TG::CSB;
+    for (int m = tid; m < F::MR; m += NTH) {
+        const int c = TG::centre(m);
+        int cell = 0xFFFF;
+        if (c >= 0) {
+            if constexpr (F::ROWT) { if ((m & 15) < N) cell = (m >> 4) * N + (m & 15); }
+            else cell = m;
+        }
+        const int rel = c - org;
+        // lanes outside this workgroup's image (other tiles, junk lanes) get a harmless in-range position: they are either
+        // never used or computed and thrown away
+        wpos[m] = (unsigned short)((c >= 0 && rel >= TG::PW + 1 && rel + TG::PW + 1 < CSL) ? rel : TG::PW + 1);
+        cellof[m] = (unsigned short)cell;
+    }
+    if constexpr (STAGE == 1) {
+        float4 *z = reinterpret_cast<float4 *>(lds);
+        for (int i = tid; i < TG::LDSA / 4; i += NTH) z[i] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    if (!any_active) return;
+    float *img2 = scratch + (size_t)grp * SG::PER_GROUP + SG::IMG1;      // the packed 64-channel board image (padding ring zeroed once)
+    if constexpr (STAGE == 1) {
+        float *planes = lds, *img1 = lds + 4 * TG::CSA;
+        for (int m = tid; m < F::MR; m += NTH) {              // games.py:86-129 encode, the cells inside this image
+            const int cell = cellof[m];
+            const int rel = TG::centre(m) - org;
+            if (cell != 0xFFFF && rel >= 0 && rel < TG::CSA) {
+                const int g = cell / F::nn, p = cell - g * F::nn;
+                const int b = b0 + g;
+                if (b < d.B) {
+                    const u64 *lf = d.leaf + (size_t)b * 8;
+                    const int ps = sym_cell(d.leaf_sym, b, p, N);
+                    if ((lf[ps >> 6] >> (ps & 63)) & 1ull) planes[rel] = 1.0f;
+                    if ((lf[4 + (ps >> 6)] >> (ps & 63)) & 1ull) planes[TG::CSA + rel] = 1.0f;
+                    if (d.leaf_last[b] == ps) planes[2 * TG::CSA + rel] = 1.0f;
+                }
+            }
+        }
+        __syncthreads();
+        const int tlo = TG::c1_lo(t), cnt = TG::c1_hi(t) - tlo + 1;
+        conv_layer<typename TG::A, 4, 32, CONV_OUT_PACKED, 2, TG::MTL1>(planes, img1, w.c1, w.c1b, wpos, cellof, wave, lane, 0, tlo, cnt);
+        __syncthreads();
+        conv_layer<typename TG::A, 32, 64, CONV_OUT_PACKED, 4, 1, F>(img1, img2, w.c2, w.c2b, wpos, cellof, wave, lane, 0, t, 1, org);
+    } else {
+        // the rows of the conv2 image this tile's windows touch: plane (cg, q) of the board image, positions org .. org + CSB
+        const float4 *src = reinterpret_cast<const float4 *>(img2);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = tid; i < 16 * TG::CSB; i += NTH) {
+            const int plane = i / TG::CSB, rel = i - plane * TG::CSB, pos = org + rel;
+            dst[i] = (pos >= 0 && pos < F::CS) ? src[plane * F::CS + pos] : float4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        float *out3 = lds + 64 * TG::CSB;                     // [co][16 cells of the tile]
+        conv_layer<typename TG::B, 64, 128, CONV_OUT3, 8, 1, typename TG::B, 16>(lds, out3, w.c3, w.c3b, wpos, cellof, wave, lane, 0, t, 1);
+        __syncthreads();
+        if (wave == 0) {                                      // policy_conv (128->4) and value_conv (128->2) of the tile's cells
+            const int q = lane >> 4, r16 = lane & 15;
+            const float4 *wp4 = reinterpret_cast<const float4 *>(w.hd) + lane;
+            float hb[4];
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) hb[rg] = (q * 4 + rg) < 6 ? w.hdb[q * 4 + rg] : 0.0f;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float *ip = out3 + q * 16 + r16;
+#pragma unroll
+            for (int s4 = 0; s4 < 8; s4++) {
+                const float4 bq = wp4[s4 * 64];
+                acc = mfma4(bq.x, ip[(s4 * 16 + 0) * 16], acc);
+                acc = mfma4(bq.y, ip[(s4 * 16 + 4) * 16], acc);
+                acc = mfma4(bq.z, ip[(s4 * 16 + 8) * 16], acc);
+                acc = mfma4(bq.w, ip[(s4 * 16 + 12) * 16], acc);
+            }
+            const int cell = cellof[t * 16 + r16];
+            if (cell != 0xFFFF) {
+                const int g = cell / F::nn, p = cell - g * F::nn;
+                const int b = b0 + g;
+                if (b < d.B && d.s_net[b] == net_id) {
+#pragma unroll
+                    for (int rg = 0; rg < 4; rg++) {
+                        const int j = q * 4 + rg;
+                        if (j < 6) {
+                            float v = acc[rg] + hb[rg];
+                            feat[(size_t)b * F::FROW + j * F::nn + p] = v > 0.0f ? v : 0.0f;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // ResidualBlock variant: stem conv(4->64)+BN+ReLU, 3 x {conv+BN+ReLU, conv+BN, +skip, ReLU}, 1x1 heads (2 policy
 // channels, 1 value channel) + BN + ReLU.  Eval-mode BatchNorm is folded into the conv weights/biases by the host
 // layer.  Two 64-channel packed images in LDS: A holds the block input/output (updated in place by the skip add),
@@ -862,122 +1068,161 @@ __global__ __launch_bounds__(ResGeo<N>::NW * 64) void k_split_res(DevState d, co
     }
 }
 
-// policy_fc (net.py:65) and value_fc1 + ReLU (net.py:69) for 16 boards per workgroup row.
-template <class G>
-__global__ __launch_bounds__(G::FCW * 64) void k_fc(DevState d, NetWeights w, int net_id, const float *__restrict__ feat,
-                                                    unsigned long long *dbgfc)
+// policy_fc (net.py:65) and value_fc1 + ReLU (net.py:69): one workgroup = 16 boards x (TPW x R) 16-output tiles of one
+// layer; it works through them in R rounds of TPW tiles, four waves per tile = the four chains of the canonical order
+// (fc_chain_groups above).  grid = (ceil(B / 16), ceil(NTP / (TPW R)) policy workgroups + ceil(4 / (TPW R)) value workgroups).
+//   * the chain's weight fragments (QG x dwordx4 per lane, L2) are requested first, before anything else, and the next
+//     round's while the current round computes;
+//   * the features the layer needs (policy or value part of the 16 boards' rows, only boards with a pending evaluation)
+//     are staged into LDS once, as [group of 16 inputs][q][board] float4: a thread loads 16 consecutive inputs of one board
+//     and stores them transposed 4 x 4, so that lane (q, board) reads the A operands of a group's four MFMAs (inputs
+//     16 g + 4 e + q, e = 0..3) with ONE conflict-free ds_read_b128;
+//   * QG x 4 dependent MFMAs per wave and round, partial sums combined through LDS in the canonical order.
+// <1, 1> (4 waves, one per SIMD, 19 workgroups per board row at n = 15) is the latency shape: few rows, many CUs free.
+// <2, 4> (8 waves, 3 workgroups per row) is the throughput shape: with every CU busy under another lane's trunk what the
+// kernel costs is the number of CU slots it has to win and the times it stages a row's features (3 instead of 19);
+// measured in the 4-lane pipeline at 15x15: one tile per workgroup 158.4 ms per ply, <4, 1> 157.6, trunk-bound floor 155.1.
+template <class G, int TPW, int R>
+__global__ __launch_bounds__(TPW * 256) void k_fc(DevState d, NetWeights w, int net_id, const float *__restrict__ feat,
+                                                  unsigned long long *dbgfc)
 {
-    __shared__ __attribute__((aligned(16))) float ft[16 * G::FSTR];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NTH = TPW * 256, TW = TPW * R;       // threads, tiles per workgroup
+    constexpr int NPW = (G::NTP + TW - 1) / TW;        // policy workgroups per board row
+    __shared__ float4 ft4[4 * G::QGMAX * 64];          // [group][q][board]
+    __shared__ float4 part[2 * TPW * 3 * 64];          // partial sums of chains 1..3, per tile and lane; double-buffered over the rounds
+    __shared__ unsigned fc_active;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chain = wv & 3, tl = wv >> 2;
     const int mb = blockIdx.x * 16;
-    const int tile = blockIdx.y * G::FCW + wave;
-    // stage the 16 boards' feature rows (16-byte vectors; rows are FROW floats, 16-B aligned)
+    const bool is_pol = (int)blockIdx.y < NPW;
+    const int tile0 = is_pol ? blockIdx.y * TW + tl : G::NTP + ((int)blockIdx.y - NPW) * TW + tl;   // this wave's tile in round 0
+    const int tile_end = is_pol ? G::NTP : G::NTP + 4;
 #ifdef AZ_STAMPS
-#define FC_STAMP(k) do { if (dbgfc && (threadIdx.x & 63) == 0) dbgfc[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FC_STAMP(k) do { if (dbgfc && (threadIdx.x & 63) == 0) dbgfc[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + ((threadIdx.x >> 6) & 7)) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define FC_STAMP(k) do { } while (0)
 #endif
     FC_STAMP(0);
-    // nothing to do for a row of 16 boards without a pending evaluation (episode tails, terminal leaves)
+    const int QG = is_pol ? G::QGP : G::QGV;           // groups per chain
+    const int K = is_pol ? G::PC * G::nn : G::VC * G::nn;
+    const int koff = is_pol ? 0 : G::PC * G::nn;
+    const int q = lane >> 4, r16 = lane & 15;
+    // a chain's weight fragments: [tile][4 QG groups, zero-padded][lane] float4 (pack_fc)
+    const float4 *wbase = reinterpret_cast<const float4 *>(is_pol ? w.pf : w.vf) + (size_t)chain * QG * 64 + lane;
+    const int tsub = is_pol ? 0 : G::NTP;
+    float4 wf[G::QGMAX];
     {
-        __shared__ int fc_active;
-        if (tid == 0) fc_active = 0;
-        __syncthreads();
-        if (tid < 16) {
-            const int b = mb + tid;
-            if (b < d.B) {
-                const int kind = d.leaf_kind[b];
-                if ((kind == LEAF_ROOT || kind == LEAF_EXPAND) && d.s_status[b] == SLOT_ACTIVE && d.s_net[b] == net_id)
-                    atomicOr(&fc_active, 1);
-            }
+        const float4 *wp4 = wbase + (size_t)((tile0 < tile_end ? tile0 : tile_end - 1) - tsub) * 4 * QG * 64;
+#pragma unroll
+        for (int j = 0; j < G::QGMAX; j++) wf[j] = j < QG ? wp4[(size_t)j * 64] : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    // the epilogues' biases, one per round, requested now so that no round waits for one
+    float bias_r[R];
+#pragma unroll
+    for (int rd = 0; rd < R; rd++) {
+        const int tile = tile0 + rd * TPW, o = (tile - tsub) * 16 + r16;
+        bias_r[rd] = (chain == 0 && tile < tile_end && (!is_pol || o < G::nn)) ? (is_pol ? w.pfb[o] : w.vfb[o]) : 0.0f;
+    }
+    // boards of this row with a pending evaluation (episode tails, terminal leaves, cache hits leave rows idle)
+    if (tid == 0) fc_active = 0u;
+    __syncthreads();
+    if (tid < 16) {
+        const int b = mb + tid;
+        if (b < d.B) {
+            const int kind = d.leaf_kind[b];
+            if ((kind == LEAF_ROOT || kind == LEAF_EXPAND) && d.s_status[b] == SLOT_ACTIVE && d.s_net[b] == net_id)
+                atomicOr(&fc_active, 1u << tid);
         }
-        __syncthreads();
-        if (!fc_active) return;
     }
-    // the LDS tail [FROW, FSTR) is zeroed: the padded k-steps of the last weight group read it (times zero weights)
-    constexpr int V = G::FROW / 4, VS = G::FSTR / 4;
-    static_assert(G::FNEED <= G::FSTR, "feature tile too narrow");
-    static_assert(16 * G::FSTR * 4 <= 150 * 1024, "k_fc feature tile exceeds LDS");
-    constexpr int NTH = G::FCW * 64;
-    constexpr int U = (16 * VS + NTH - 1) / NTH;
-    float4 tmp[U];
+    __syncthreads();
+    const unsigned active = fc_active;
+    if (!active) return;
+    // stage: unit u = (group g, board i); inputs beyond K (chain padding) and idle boards are zeros
+    const bool vec4 = (koff & 3) == 0;                 // the ResidualBlock net's value inputs start at 2 n^2: 8-byte aligned for odd n
+    for (int u = tid; u < 4 * QG * 16; u += NTH) {
+        const int g = u >> 4, i = u & 15;
+        float x[16];
 #pragma unroll
-    for (int u = 0; u < U; u++) {            // all loads in flight before the first LDS store
-        const int idx = tid + NTH * u;
-        const int i = idx / VS, c = idx - i * VS;
-        const int b = mb + i;
-        tmp[u] = float4{0.f, 0.f, 0.f, 0.f};
-        if (idx < 16 * VS && b < d.B && c < V) tmp[u] = reinterpret_cast<const float4 *>(feat + (size_t)b * G::FROW)[c];
-    }
+        for (int e = 0; e < 16; e++) x[e] = 0.0f;
+        const int k0 = 16 * g;
+        if (((active >> i) & 1u) && k0 < K) {
+            const float *src = feat + (size_t)(mb + i) * G::FROW + koff + k0;
+            if (vec4) {
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-        const int idx = tid + NTH * u;
-        const int i = idx / VS, c = idx - i * VS;
-        if (idx < 16 * VS) reinterpret_cast<float4 *>(ft + i * G::FSTR)[c] = tmp[u];
+                for (int a = 0; a < 4; a++)
+                    if (k0 + 4 * a < K) {
+                        const float4 v = reinterpret_cast<const float4 *>(src)[a];
+                        x[4 * a] = v.x; x[4 * a + 1] = v.y; x[4 * a + 2] = v.z; x[4 * a + 3] = v.w;
+                    }
+            } else {
+#pragma unroll
+                for (int a = 0; a < 8; a++)
+                    if (k0 + 2 * a < K) {
+                        const float2 v = reinterpret_cast<const float2 *>(src)[a];
+                        x[2 * a] = v.x; x[2 * a + 1] = v.y;
+                    }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++) x[e] = k0 + e < K ? x[e] : 0.0f;     // the row's next part / tail is not this layer's input
+        }
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) ft4[(g * 4 + qq) * 16 + i] = float4{x[qq], x[4 + qq], x[8 + qq], x[12 + qq]};
     }
     __syncthreads();
     FC_STAMP(1);
-    if (tile >= G::NTP + 4) return;
-    const int q = lane >> 4, r16 = lane & 15;
-    const bool is_pol = tile < G::NTP;
-    const int KS = is_pol ? G::KSP : G::KSV;
-    const int KS4 = (KS + 3) / 4;
-    constexpr int CH = 8;                              // weight groups (of 4 k-steps) per chunk
-    const int NCH = (KS4 + CH - 1) / CH;               // the packed weights are zero-padded to whole chunks of 16 groups
-    const float4 *wp4 = reinterpret_cast<const float4 *>(is_pol ? w.pf : w.vf) +
-                        (size_t)(is_pol ? tile : tile - G::NTP) * (is_pol ? G::KS4P_PAD : G::KS4V_PAD) * 64 + lane;
-    const float *ip = ft + r16 * G::FSTR + (is_pol ? 0 : G::PC * G::nn) + q;
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    // One k-ordered MFMA chain.  Both operand streams are double-buffered a whole chunk (32 MFMAs) ahead: the
-    // weight fragments come from L2, the feature fragments from LDS; the sched_barrier pins the loads above the chain.
-    float4 bcur[CH], bnxt[CH];
-    float acur[CH][4], anxt[CH][4];
+    const float4 *fp = ft4 + (chain * QG * 4 + q) * 16 + r16;
 #pragma unroll
-    for (int j = 0; j < CH; j++) {
-        bcur[j] = wp4[(size_t)j * 64];
+    for (int rd = 0; rd < R; rd++) {
+        const int tile = tile0 + rd * TPW;
+        const bool has_tile = tile < tile_end;
+        float4 wn[G::QGMAX];                           // the next round's fragments fly while this round computes
+        if (R > 1) {
+            const int tn = tile + TPW < tile_end ? tile + TPW : tile_end - 1;
+            const float4 *wp4 = wbase + (size_t)(tn - tsub) * 4 * QG * 64;
 #pragma unroll
-        for (int e = 0; e < 4; e++) acur[j][e] = ip[j * 16 + e * 4];
-    }
-    for (int c = 0; c < NCH; c++) {
-        const int cn = c + 1 < NCH ? c + 1 : c;
-        const float *ipn = ip + cn * CH * 16;
-#pragma unroll
-        for (int j = 0; j < CH; j++) {
-            bnxt[j] = wp4[(size_t)(cn * CH + j) * 64];
-#pragma unroll
-            for (int e = 0; e < 4; e++) anxt[j][e] = ipn[j * 16 + e * 4];
+            for (int j = 0; j < G::QGMAX; j++) wn[j] = (rd + 1 < R && j < QG) ? wp4[(size_t)j * 64] : float4{0.f, 0.f, 0.f, 0.f};
         }
-        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (has_tile) {
 #pragma unroll
-        for (int j = 0; j < CH; j++) {
-            acc = mfma4(acur[j][0], bcur[j].x, acc);
-            acc = mfma4(acur[j][1], bcur[j].y, acc);
-            acc = mfma4(acur[j][2], bcur[j].z, acc);
-            acc = mfma4(acur[j][3], bcur[j].w, acc);
+            for (int j = 0; j < G::QGMAX; j++)
+                if (j < QG) {
+                    const float4 af = fp[j * 64];
+                    acc = mfma4(af.x, wf[j].x, acc);
+                    acc = mfma4(af.y, wf[j].y, acc);
+                    acc = mfma4(af.z, wf[j].z, acc);
+                    acc = mfma4(af.w, wf[j].w, acc);
+                }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        float4 *pr = part + (rd & 1) * TPW * 3 * 64;
+        if (chain) pr[(tl * 3 + chain - 1) * 64 + lane] = float4{acc[0], acc[1], acc[2], acc[3]};
+        __syncthreads();
+        if (!chain && has_tile) {
+            const float4 p1 = pr[(tl * 3) * 64 + lane], p2 = pr[(tl * 3 + 1) * 64 + lane], p3 = pr[(tl * 3 + 2) * 64 + lane];
+            const float r[4] = {(acc[0] + p1.x) + (p2.x + p3.x), (acc[1] + p1.y) + (p2.y + p3.y),
+                                (acc[2] + p1.z) + (p2.z + p3.z), (acc[3] + p1.w) + (p2.w + p3.w)};
+            // only slots with a pending evaluation are written: the row of a slot whose evaluation came from the cache (or
+            // that waits on a terminal leaf) must stay as it is
 #pragma unroll
-        for (int j = 0; j < CH; j++) {
-            bcur[j] = bnxt[j];
+            for (int rg = 0; rg < 4; rg++) {
+                const int i = q * 4 + rg, b = mb + i;
+                if ((active >> i) & 1u) {
+                    if (is_pol) {
+                        const int j = tile * 16 + r16;
+                        if (j < G::nn) d.logits[(size_t)b * G::RW + j] = r[rg] + bias_r[rd];
+                    } else {
+                        const int o = (tile - G::NTP) * 16 + r16;
+                        const float v = r[rg] + bias_r[rd];
+                        d.vhid[(size_t)b * 64 + o] = v > 0.0f ? v : 0.0f;
+                    }
+                }
+            }
+        }
+        if (R > 1) {
 #pragma unroll
-            for (int e = 0; e < 4; e++) acur[j][e] = anxt[j][e];
+            for (int j = 0; j < G::QGMAX; j++) wf[j] = wn[j];
         }
     }
     FC_STAMP(2);
-    // only slots with a pending evaluation are written: the row of a slot whose evaluation came from the cache (or that
-    // waits on a terminal leaf) must stay as it is
-#pragma unroll
-    for (int rg = 0; rg < 4; rg++) {
-        int b = mb + q * 4 + rg;
-        if (b < d.B && d.s_net[b] == net_id && leaf_needs_net(d.leaf_kind[b]) && d.s_status[b] == SLOT_ACTIVE) {
-            if (is_pol) {
-                int j = tile * 16 + r16;
-                if (j < G::nn) d.logits[(size_t)b * G::RW + j] = acc[rg] + w.pfb[j];
-            } else {
-                int i = (tile - G::NTP) * 16 + r16;
-                float v = acc[rg] + w.vfb[i];
-                d.vhid[(size_t)b * 64 + i] = v > 0.0f ? v : 0.0f;
-            }
-        }
-    }
 }

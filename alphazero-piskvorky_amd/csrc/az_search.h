@@ -184,10 +184,11 @@ __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edg
     }
 }
 
-// policy_fc (net.py:65) and value_fc1 + ReLU (net.py:69) of the workgroup's GP boards: k_fc's MFMA chain (az_net.h) with
-// the board rows beyond GP supplied as zeros from registers -- one 16-output tile per wave, the weight fragments streamed
-// from L2 a whole chunk (32 MFMAs) ahead, the feature rows read from LDS.  featl rows have stride NG::FSTR with a zero
-// tail, which the padded k-steps of the last weight group read (times zero weights).
+// policy_fc (net.py:65) and value_fc1 + ReLU (net.py:69) of the workgroup's GP boards in the canonical order of az_net.h
+// (fc_chain_groups): one 16-output tile per wave, its FOUR chains in four independent accumulators (the MFMAs of different
+// chains do not wait for each other), combined as ((p0 + p1) + (p2 + p3)) + bias.  Board rows beyond GP are zeros from
+// registers; the weight fragments of a tile (4 QG groups) are requested up front from L2; the feature rows are read from
+// LDS: featl row = [policy inputs | zeros up to 64 QGP][value inputs | zeros up to 64 QGV], stride NG::FSTR.
 template <class PG, class NG>
 __device__ __forceinline__ void fc_mfma(const NetWeights &w, const float *featl, float *logits_l, float *vhid_l, int wave, int lane)
 {
@@ -195,58 +196,44 @@ __device__ __forceinline__ void fc_mfma(const NetWeights &w, const float *featl,
     if (tile >= NG::NTP + 4) return;
     const int q = lane >> 4, r16 = lane & 15;
     const bool is_pol = tile < NG::NTP;
-    const int KS = is_pol ? NG::KSP : NG::KSV;
-    const int KS4 = (KS + 3) / 4;
-    constexpr int CH = 8;                              // weight groups (of 4 k-steps) per chunk
-    const int NCH = (KS4 + CH - 1) / CH;               // the packed weights are zero-padded to whole chunks of 16 groups
+    const int QG = is_pol ? NG::QGP : NG::QGV;
     const float4 *wp4 = reinterpret_cast<const float4 *>(is_pol ? w.pf : w.vf) +
-                        (size_t)(is_pol ? tile : tile - NG::NTP) * (is_pol ? NG::KS4P_PAD : NG::KS4V_PAD) * 64 + lane;
+                        (size_t)(is_pol ? tile : tile - NG::NTP) * 4 * QG * 64 + lane;
     const bool row_ok = r16 < PG::G;
-    const float *ip = featl + (row_ok ? r16 : 0) * NG::FSTR + (is_pol ? 0 : NG::PC * NG::nn) + q;
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    float4 bcur[CH], bnxt[CH];
-    float acur[CH][4], anxt[CH][4];
+    const float *ip = featl + (row_ok ? r16 : 0) * NG::FSTR + (is_pol ? 0 : NG::VOFFL) + q;
+    f32x4 acc[4];
 #pragma unroll
-    for (int j = 0; j < CH; j++) {
-        bcur[j] = wp4[(size_t)j * 64];
+    for (int c = 0; c < 4; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 bw[4][NG::QGMAX];
 #pragma unroll
-        for (int e = 0; e < 4; e++) acur[j][e] = row_ok ? ip[j * 16 + e * 4] : 0.0f;
-    }
-    for (int c = 0; c < NCH; c++) {
-        const int cn = c + 1 < NCH ? c + 1 : c;
-        const float *ipn = ip + cn * CH * 16;
+    for (int c = 0; c < 4; c++)
 #pragma unroll
-        for (int j = 0; j < CH; j++) {
-            bnxt[j] = wp4[(size_t)(cn * CH + j) * 64];
+        for (int j = 0; j < NG::QGMAX; j++) bw[c][j] = j < QG ? wp4[(size_t)(c * QG + j) * 64] : float4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < 4; e++) anxt[j][e] = row_ok ? ipn[j * 16 + e * 4] : 0.0f;
+    for (int j = 0; j < NG::QGMAX; j++)
+        if (j < QG) {
+            float a[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) a[c][e] = row_ok ? ip[(c * QG + j) * 16 + e * 4] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    acc[c] = mfma4(a[c][e], e == 0 ? bw[c][j].x : e == 1 ? bw[c][j].y : e == 2 ? bw[c][j].z : bw[c][j].w, acc[c]);
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < CH; j++) {
-            acc = mfma4(acur[j][0], bcur[j].x, acc);
-            acc = mfma4(acur[j][1], bcur[j].y, acc);
-            acc = mfma4(acur[j][2], bcur[j].z, acc);
-            acc = mfma4(acur[j][3], bcur[j].w, acc);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < CH; j++) {
-            bcur[j] = bnxt[j];
-#pragma unroll
-            for (int e = 0; e < 4; e++) acur[j][e] = anxt[j][e];
-        }
-    }
 #pragma unroll
     for (int rg = 0; rg < 4; rg++) {
         const int g = q * 4 + rg;                      // board row of this accumulator register
         if (g < PG::G) {
+            const float r = (acc[0][rg] + acc[1][rg]) + (acc[2][rg] + acc[3][rg]);
             if (is_pol) {
                 const int j = tile * 16 + r16;
-                if (j < NG::nn) logits_l[g * PG::RW + j] = acc[rg] + w.pfb[j];
+                if (j < NG::nn) logits_l[g * PG::RW + j] = r + w.pfb[j];
             } else {
                 const int i = (tile - NG::NTP) * 16 + r16;
-                const float v = acc[rg] + w.vfb[i];
+                const float v = r + w.vfb[i];
                 vhid_l[g * 64 + i] = v > 0.0f ? v : 0.0f;
             }
         }
@@ -265,7 +252,7 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
     __shared__ __attribute__((aligned(16))) float lds[PG::LDSF];
     __shared__ unsigned short wpos[PG::MR];
     __shared__ unsigned short cellof[PG::MR];
-    __shared__ __attribute__((aligned(16))) float featl[GP * NG::FSTR];       // head-conv outputs, rows zero beyond 6 n^2
+    __shared__ __attribute__((aligned(16))) float featl[GP * NG::FSTR];       // head-conv outputs: [policy inputs | zeros][value inputs | zeros] per board (fc_mfma)
     __shared__ float logits_l[GP * PG::RW];
     __shared__ float vhid_l[GP * 64];
     __shared__ unsigned path_l[GP][PG::PATH];
@@ -380,7 +367,7 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
                             const int j = q * 4 + rg;     // head channel: 0-3 policy_conv, 4-5 value_conv (net.py:64,69 flatten order)
                             if (j < 6) {
                                 float v = acc[rg] + hb[rg];
-                                featl[g * NG::FSTR + j * PG::nn + p] = v > 0.0f ? v : 0.0f;
+                                featl[g * NG::FSTR + (j < 4 ? j * PG::nn : NG::VOFFL + (j - 4) * PG::nn) + p] = v > 0.0f ? v : 0.0f;
                             }
                         }
                     }

@@ -55,7 +55,7 @@ class ModelEvaluator:
             seed0 = parallel.broadcast_seed(seed0, dev)
         r = eng.arena(mine, seed0=seed0 + lo, temperature_table=T) if mine > 0 else {"wins": 0, "losses": 0, "draws": 0, "total": 0, "win_rate": 0.0}
         if world > 1:
-            w, l, d = parallel.all_reduce_tally(r["wins"], r["losses"], r["draws"], dev)
+            w, l, d = parallel.all_reduce_tally(r["wins"], r["losses"], r["draws"], dev, engine=eng)
             tot = w + l + d
             r = dict(r, wins=w, losses=l, draws=d, total=tot, win_rate=(w + 0.5 * d) / tot if tot else 0.0)   # evaluator.py:106-109
         if debug:

@@ -1,18 +1,15 @@
 """Multi-GPU sharding of self-play.
 
 Games never interact (self_play.py:41-73), so ranks play disjoint game ids with no data-path
-collective; the only exchange is at episode end: an all-gather of per-rank record counts, then an
-all-gather -- or, for the reference's single trainer, a gather to one rank -- of the packed (planes, last
-move, pi, z) records padded to the largest count: RCCL over xGMI when the process group is "nccl", gloo
-on CPU in the tests.  This replaces result_queue.put/get (self_play.py:73,140).
+collective; the only exchange is at episode end.  It lives INSIDE the C-ABI library (include/az_engine.h az_dist_*:
+ncclAllGather of the record counts, then grouped ncclSend / ncclRecv of the true sizes to the rank that trains -- or to
+every rank -- on the engine's own stream, and the arena's tally as one ncclAllReduce); this module only bootstraps the
+library's communicator from a torch.distributed "nccl" group (128 bytes of unique id over the group) and calls it.
+With a gloo group (the CPU tests, ranks sharing one GPU) the same exchange runs on torch.distributed collectives staged
+through the host, padded to the largest count.  This replaces result_queue.put/get (self_play.py:73,140).
 """
 import numpy as np
 import torch
-
-
-def shard_games(num_games, rank, world):
-    """Game ids of this rank: g with g % world == rank (static partition replacing the task queue, self_play.py:117-118)."""
-    return list(range(rank, num_games, world))
 
 
 def _dist_on(force):
@@ -54,10 +51,38 @@ def all_gather_packed(packed, count, record_bytes, dst=None, force=False):
     return [o[: c * record_bytes] for o, c in zip(outs, counts)], counts
 
 
+def engine_comm(engine, device, force=False):
+    """True when `engine` holds an RCCL communicator over the ranks of the current torch.distributed group, creating it on
+    first use: rank 0 draws the unique id and the group carries its 128 bytes to everybody.  Only for "nccl" groups (a gloo
+    group means CPU tests or ranks sharing a GPU, which RCCL refuses)."""
+    import torch.distributed as td
+    if not _dist_on(force) or td.get_backend() != "nccl":
+        return False
+    world, rank = td.get_world_size(), td.get_rank()
+    if engine.dist_world() == world and getattr(engine, "_dist_group_ok", False):
+        return True
+    from ._capi import AZ_DIST_ID_BYTES, dist_unique_id
+    idt = torch.zeros(AZ_DIST_ID_BYTES, dtype=torch.uint8, device=device)
+    if rank == 0:
+        idt.copy_(torch.frombuffer(bytearray(dist_unique_id()), dtype=torch.uint8))
+    td.broadcast(idt, 0)
+    engine.dist_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+    engine._dist_group_ok = True
+    return True
+
+
 def gather_packed_records(engine, device, dst=None, force=False):
     """Pack this rank's episode records on the device and exchange them.  Returns (uint8 tensor of all records
     in rank order -- empty on the ranks a gather-to-root leaves out --, per-rank counts)."""
     import torch.distributed as td
+    if engine_comm(engine, device, force):
+        # the library's own exchange: true sizes, only to the ranks that asked
+        counts = engine.dist_counts()
+        receive = dst is None or dst == engine.dist_rank()
+        total = sum(counts) if receive else 0
+        out = torch.empty(max(total, 1) * engine.record_bytes, dtype=torch.uint8, device=device)
+        engine.dist_gather_records(-1 if dst is None else int(dst), out.data_ptr() if receive else 0)
+        return out[: total * engine.record_bytes], counts
     count = engine.last_records
     packed = torch.zeros(max(count, 1) * engine.record_bytes, dtype=torch.uint8, device=device)
     if count:
@@ -81,11 +106,15 @@ def arena_block(num_games, rank, world):
     return lo, min(lo + per, num_games)
 
 
-def all_reduce_tally(wins, losses, draws, device, force=False):
-    """Arena tally exchange: sum of three integers over the ranks (RCCL with an nccl group, gloo otherwise)."""
+def all_reduce_tally(wins, losses, draws, device, force=False, engine=None):
+    """Arena tally exchange: sum of three integers over the ranks -- az_dist_allreduce_sum inside the library
+    when an engine is given and the group is RCCL, torch.distributed otherwise (gloo)."""
     import torch.distributed as td
     if not _dist_on(force):
         return int(wins), int(losses), int(draws)
+    if engine is not None and engine_comm(engine, device, force):
+        w, l, d = engine.dist_allreduce_sum([wins, losses, draws])
+        return w, l, d
     on_dev = td.get_backend() == "nccl"
     t = torch.tensor([wins, losses, draws], dtype=torch.int64, device=device if on_dev else "cpu")
     td.all_reduce(t, op=td.ReduceOp.SUM)

@@ -45,7 +45,11 @@ def cpu_baseline(n, k, sims, sd, budget_games):
     one game per thread like self_play.py:29-45, first 2 plies of `budget_games` games."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as orc
-    cores = min(os.cpu_count() or 1, 64)
+    try:
+        avail = len(os.sched_getaffinity(0))      # the CPUs this job may use (the box grants a share of its hardware threads)
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = min(avail, 64)
     o = orc.Oracle(n, k, sims)
     net = orc.Net(n, sd)
     plies = 2

@@ -191,6 +191,35 @@ int az_selfplay_records(az_engine *e, uint8_t *boards, uint8_t *movers, int16_t 
 int64_t az_record_bytes(const az_engine *e);
 int az_selfplay_pack(az_engine *e, void *packed_dev);
 
+/* ---- multi-GPU: the episode-end exchange inside the library (replaces result_queue.put / get across workers,
+ * self_play.py:73,140, and the tally of evaluator.py:106-109 across ranks) ----
+ * One engine per rank = per GPU; ranks play disjoint game ids (the caller passes seed0 + first id and its share of the
+ * games to az_selfplay / az_arena), so the only communication is at episode end.  The library calls RCCL directly on the
+ * engine's own stream (librccl.so.1 is bound at run time: the copy a host framework has already loaded, else the
+ * system's); nothing here needs torch.distributed.
+ *   az_dist_unique_id   one rank creates the communicator id (ncclGetUniqueId) and hands its AZ_DIST_ID_BYTES bytes to the
+ *                       other ranks over whatever channel the caller has (a file, MPI, a launcher's store);
+ *   az_dist_init        collective: every rank joins with the same id (ncclCommInitRank on the engine's device);
+ *   az_dist_counts      collective: counts[world] = records of every rank's last episode (ncclAllGather of one int64);
+ *   az_dist_gather_records  collective: the packed records (az_record_bytes each, as az_selfplay_pack writes them) of all
+ *                       ranks, in rank order, into packed_dev on rank dst -- grouped ncclSend / ncclRecv of the TRUE sizes, no
+ *                       padding to the largest rank, nothing sent to ranks that do not train; dst = -1: every rank
+ *                       receives everything.  packed_dev (DEVICE) needs room for sum(counts) records on a receiving rank
+ *                       and may be NULL elsewhere.  A rank without an episode contributes 0 records.
+ *   az_dist_allreduce_sum   collective: element-wise sum of n int64 values over the ranks (the arena's wins / losses / draws);
+ *   az_dist_broadcast   collective: bytes of a DEVICE buffer from rank root to every rank (new weights after train_step).
+ * az_dist_rank / az_dist_world: 0 / 1 before az_dist_init.  Errors: AZ_ERR_STATE without az_dist_init, AZ_ERR_HIP with the
+ * RCCL message in az_last_error when RCCL cannot be loaded or a call fails. */
+#define AZ_DIST_ID_BYTES 128
+int az_dist_unique_id(void *id);
+int az_dist_init(az_engine *e, const void *id, int rank, int world);
+int az_dist_rank(const az_engine *e);
+int az_dist_world(const az_engine *e);
+int az_dist_counts(az_engine *e, int64_t *counts);
+int az_dist_gather_records(az_engine *e, int dst, void *packed_dev);
+int az_dist_allreduce_sum(az_engine *e, int64_t *values, int n);
+int az_dist_broadcast(az_engine *e, void *buf_dev, int64_t bytes, int root);
+
 /* Training examples: (state f32[4,n,n], pi f32[n,n], z) with the augmentation of
  * SelfPlayManager._augment_symmetries fused into the encode (self_play.py:94-108,146-148):
  * AZ_AUG_REFERENCE4 reproduces the reference (state rot k*90deg, pi rot 90deg once, Q16),

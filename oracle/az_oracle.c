@@ -318,6 +318,23 @@ static void conv3x3_core(int n, int cin, int cout, const float *in, const float 
 }
 
 /* net.py:55-72 forward on one encoded state; outputs raw logits[nn] and tanh value */
+/* Canonical order of an FC output over K inputs (shared by definition with the HIP engine, csrc/az_net.h fc_chain_groups):
+ * the inputs are cut into FOUR contiguous blocks of 16 * ceil(ceil(K / 16) / 4) inputs; each block is one k-ordered fmaf chain
+ * from +0 and the output is (p0 + p1) + (p2 + p3), bias added by the caller.  (Round 3: was a single chain.  torch's own
+ * order is unknowable either way -- net.py:65,69 -- and the result stays within the tolerances the tests grant it.) */
+static float fc_dot(const float *x, const float *w, int K)
+{
+    const int blk = 16 * ((((K + 15) / 16) + 3) / 4);
+    float p[4];
+    for (int c = 0; c < 4; c++) {
+        float acc = 0.0f;
+        const int k1 = (c + 1) * blk < K ? (c + 1) * blk : K;
+        for (int k = c * blk; k < k1; k++) acc = fmaf(x[k], w[k], acc);
+        p[c] = acc;
+    }
+    return (p[0] + p[1]) + (p[2] + p[3]);
+}
+
 static void net_forward(const orc_net *N, const float *planes, float *logits, float *value)
 {
     int n = N->n, nn = n * n;
@@ -343,18 +360,10 @@ static void net_forward(const orc_net *N, const float *planes, float *logits, fl
             float v = acc + N->vcb[0];
             vf[pos] = v > 0.0f ? v : 0.0f;
         }
-        for (int j = 0; j < nn; j++) {
-            float acc = 0.0f;
-            const float *wr = N->pfw + (size_t)j * 2 * nn;
-            for (int q = 0; q < 2 * nn; q++) acc = fmaf(pf[q], wr[q], acc);
-            logits[j] = acc + N->pfb[j];
-        }
+        for (int j = 0; j < nn; j++) logits[j] = fc_dot(pf, N->pfw + (size_t)j * 2 * nn, 2 * nn) + N->pfb[j];
         float hh[64];
         for (int i = 0; i < 64; i++) {
-            float acc = 0.0f;
-            const float *wr = N->v1w + (size_t)i * nn;
-            for (int q = 0; q < nn; q++) acc = fmaf(vf[q], wr[q], acc);
-            float v = acc + N->v1b[i];
+            float v = fc_dot(vf, N->v1w + (size_t)i * nn, nn) + N->v1b[i];
             hh[i] = v > 0.0f ? v : 0.0f;
         }
         float acc = 0.0f;
@@ -379,18 +388,10 @@ static void net_forward(const orc_net *N, const float *planes, float *logits, fl
             vf[c * nn + pos] = v > 0.0f ? v : 0.0f;
         }
     }
-    for (int j = 0; j < nn; j++) {
-        float acc = 0.0f;
-        const float *wr = N->pfw + (size_t)j * 4 * nn;
-        for (int q = 0; q < 4 * nn; q++) acc = fmaf(pf[q], wr[q], acc);
-        logits[j] = acc + N->pfb[j];
-    }
+    for (int j = 0; j < nn; j++) logits[j] = fc_dot(pf, N->pfw + (size_t)j * 4 * nn, 4 * nn) + N->pfb[j];
     float h[64];
     for (int i = 0; i < 64; i++) {
-        float acc = 0.0f;
-        const float *wr = N->v1w + (size_t)i * 2 * nn;
-        for (int q = 0; q < 2 * nn; q++) acc = fmaf(vf[q], wr[q], acc);
-        float v = acc + N->v1b[i];
+        float v = fc_dot(vf, N->v1w + (size_t)i * 2 * nn, 2 * nn) + N->v1b[i];
         h[i] = v > 0.0f ? v : 0.0f;
     }
     float acc = 0.0f;

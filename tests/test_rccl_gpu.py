@@ -36,7 +36,29 @@ for dst in (None, 0):
     assert packed.is_cuda and counts == [e.last_records]
     assert torch.equal(packed, want)
 out["records"] = int(e.last_records)
+assert e.dist_world() == 1 and e.dist_rank() == 0        # parallel.py made the library's own communicator from the group
 e.close()
+# the same exchange with no torch.distributed in the call path: the C-ABI's az_dist_* on a communicator of its own
+from alphazero_piskvorky_amd import _capi
+e2 = az.Engine(5, 4, 16, 8, synthetic=True)
+try:
+    e2.dist_counts(); raise SystemExit("az_dist_counts before az_dist_init must fail")
+except _capi.AzError:
+    pass
+e2.dist_init(_capi.dist_unique_id(), 0, 1)
+assert e2.dist_counts() == [0]                           # no episode yet: this rank contributes nothing
+e2.selfplay(5, seed0=9)
+want2 = torch.zeros(e2.last_records * e2.record_bytes, dtype=torch.uint8, device=dev)
+e2.pack_into(want2.data_ptr()); torch.cuda.synchronize()
+assert e2.dist_counts() == [e2.last_records]
+for dst in (0, -1):
+    got = torch.zeros_like(want2)
+    e2.dist_gather_records(dst, got.data_ptr())
+    assert torch.equal(got, want2)
+assert e2.dist_allreduce_sum([7, 2, 1]) == [7, 2, 1]
+t = torch.arange(1000, dtype=torch.int32, device=dev); keep = t.clone()
+e2.dist_broadcast(t.data_ptr(), t.numel() * 4, 0); assert torch.equal(t, keep)
+e2.close()
 assert parallel.all_reduce_tally(7, 2, 1, dev, force=True) == (7, 2, 1)
 assert parallel.broadcast_seed(4242, dev, force=True) == 4242
 net = GomokuNet(board_size=5).to(dev)
