@@ -26,8 +26,10 @@ PROMOTION_THRESHOLD = 0.55          # promoter.py:19, strict ">" with draws coun
 
 
 def run(episodes, games, sims, eval_games, device="cuda:0", seed=0, model_dir=None, log=print, device_replay=False,
-        subtree_reuse=False, trunk="f32"):
-    """device_replay=True keeps the examples on the GPU from the episode-end gather to the optimizer step (packed records
+        subtree_reuse=False, trunk="f32", eval_sims=None):
+    """eval_sims: simulations per move in the arena (evaluator.py:53-62 takes NUM_EVAL_SIMULATIONS = 200 whatever the
+    self-play count is; main() passes that constant); None = as many as self-play, which keeps small test runs short.
+    device_replay=True keeps the examples on the GPU from the episode-end gather to the optimizer step (packed records
     in a device ring, batches unpacked + augmented by az_examples_gather) instead of materialising Python tuples."""
     torch.manual_seed(seed)
     n = C.BOARD_SIZE
@@ -45,7 +47,7 @@ def run(episodes, games, sims, eval_games, device="cuda:0", seed=0, model_dir=No
     ring = None
     history = []
     saved_eval_sims = C.NUM_EVAL_SIMULATIONS
-    C.NUM_EVAL_SIMULATIONS = sims
+    C.NUM_EVAL_SIMULATIONS = sims if eval_sims is None else eval_sims
     try:
         for ep in range(episodes):
             t0 = time.perf_counter()
@@ -106,7 +108,7 @@ def main():
         td.init_process_group("nccl", device_id=torch.device("cuda", local))
         a.device = f"cuda:{local}"
     run(a.episodes, a.games, a.sims, a.eval_games, a.device, model_dir=a.model_dir, device_replay=a.device_replay,
-        subtree_reuse=a.subtree_reuse, trunk=a.trunk)
+        subtree_reuse=a.subtree_reuse, trunk=a.trunk, eval_sims=C.NUM_EVAL_SIMULATIONS)
     if world > 1:
         td.barrier()
         td.destroy_process_group()

@@ -20,6 +20,9 @@ Fixture families:
   G7 zlabels.json           the z truth table of alphazero/tests/tests.py:11-22
   G4-full netgame_full_{n}x{k}.npz  real-net plies at the BASELINE search sizes: 15x15/400 sims (7 plies), 9x9/200 sims (24 plies)
   G4-complete netgame_complete_15x5.npz  ONE whole reference game at 15x15 / 400 sims (python make_golden.py complete)
+  G8 resnet_ckpt_5.npz      the VALUES of one historical ResidualBlock checkpoint of the reference (weights-only load of
+                            alphazero/models/old/model_20250728_225053.pt: data, no code) + the outputs of the BUILD's torch module
+                            loaded with them (the reference ships no forward for this variant)  (python make_golden.py resnet)
 """
 import json
 import os
@@ -494,8 +497,52 @@ def worker_full(n, k, complete=False):
         **{key: np.array([c[key] for c in recs]) for key in recs[0]})
 
 
+def worker_resnet_checkpoint():
+    """G8: values of a real ResidualBlock checkpoint + the build's own torch forward on seeded positions.  Nothing of the
+    reference is imported or executed: torch.load(weights_only=True) reads tensors only."""
+    import torch
+    torch.set_num_threads(1)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from alphazero_piskvorky_amd.net import GomokuResNet
+    src = "/root/reference/alphazero/models/old/model_20250728_225053.pt"
+    sd = torch.load(src, map_location="cpu", weights_only=True)
+    sd = {k: v for k, v in sd.items() if not k.endswith("num_batches_tracked")}
+    n = 5
+    m = GomokuResNet(board_size=n)
+    missing = m.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all(k.endswith("num_batches_tracked") for k in missing.missing_keys), missing
+    m.eval()
+    rs = np.random.RandomState(58)
+    nn = n * n
+    boards, players, lasts, planes = [], [], [], []
+    for t in range(24):
+        stones = int(rs.randint(0, nn - 3))
+        b = np.zeros(nn, np.uint8)
+        cells = rs.permutation(nn)[:stones]
+        b[cells[0::2]] = 1
+        b[cells[1::2]] = 2
+        pl = 1 + (stones & 1)
+        la = int(cells[-1]) if stones else -1
+        x = np.zeros((4, n, n), np.float32)                     # games.py:86-129 encode
+        x[0] = (b == pl).reshape(n, n); x[1] = (b == 3 - pl).reshape(n, n)
+        if la >= 0:
+            x[2].reshape(-1)[la] = 1.0
+        boards.append(b); players.append(pl); lasts.append(la); planes.append(x)
+    with torch.no_grad():
+        lg, v = m(torch.tensor(np.stack(planes)))
+        P = torch.softmax(lg, 1)
+    np.savez_compressed(os.path.join(HERE, "resnet_ckpt_5.npz"), n=n, source=os.path.basename(src),
+                        boards=np.array(boards), players=np.array(players, np.uint8), lasts=np.array(lasts, np.int16),
+                        logits=lg.numpy(), P=P.numpy(), value=v.numpy().reshape(-1),
+                        versions=json.dumps({"numpy": np.__version__, "torch": torch.__version__}),
+                        **{"w__" + k: t.numpy() for k, t in sd.items()})
+    print("resnet_ckpt_5.npz written:", len(sd), "tensors,", float(v.abs().max()), "max |value|")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) == 4 and sys.argv[3] in ("full", "complete"):
+    if len(sys.argv) == 2 and sys.argv[1] == "resnet":
+        worker_resnet_checkpoint()
+    elif len(sys.argv) == 4 and sys.argv[3] in ("full", "complete"):
         worker_full(int(sys.argv[1]), int(sys.argv[2]), complete=sys.argv[3] == "complete")
     elif len(sys.argv) == 2 and sys.argv[1] == "complete":
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")

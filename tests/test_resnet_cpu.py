@@ -60,6 +60,37 @@ def test_oracle_resnet_forward_matches_torch_definition():
             assert abs(v - float(tv)) <= 5e-6
 
 
+def _checkpoint_fixture():
+    from tests.util import load
+    z = load("resnet_ckpt_5.npz")
+    return z, {k[3:]: z[k] for k in z.files if k.startswith("w__")}
+
+
+def test_real_checkpoint_values_through_the_oracle_and_the_build_torch_module():
+    """tests/golden/resnet_ckpt_5.npz: the VALUES of the reference's historical checkpoint model_20250728_225053.pt (a
+    weights-only load in the build container) and the outputs the build's GomokuResNet gives with them.  The parameter
+    set is exactly the ABI above; the module reproduces the recorded outputs here, and the oracle (BatchNorm folded on the
+    host) meets them within the ResidualBlock tolerances.  Parity against the REFERENCE stays unpinned: it has no forward."""
+    z, sd = _checkpoint_fixture()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == CHECKPOINT_KEYS_5x5
+    n = int(z["n"])
+    m = GomokuResNet(board_size=n)
+    m.load_state_dict({k: torch.tensor(v) for k, v in sd.items()}, strict=False)
+    m.eval()
+    net = orc.Net(n, resnet_tensors=fold_resnet_state_dict(sd))
+    o = orc.Oracle(n, 4, 1)
+    assert float(np.abs(z["value"]).max()) > 0.05 and float(z["P"].max()) > 0.1       # a trained net, not an initialisation
+    for i in range(len(z["players"])):
+        planes = o.encode(z["boards"][i], int(z["players"][i]), int(z["lasts"][i]))
+        with torch.no_grad():
+            tl, tv = m(torch.tensor(planes)[None])
+        np.testing.assert_allclose(tl.numpy()[0], z["logits"][i], rtol=0, atol=2e-6)     # the module here == the module at fixture time
+        lg, P, v = net.eval(planes)
+        np.testing.assert_allclose(lg, z["logits"][i], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(P, z["P"][i], rtol=0, atol=1e-6)
+        assert abs(v - float(z["value"][i])) <= 5e-6
+
+
 def test_bn_folding_is_exact_in_float64():
     sd = synthetic_resnet_state_dict(5)
     t = fold_resnet_state_dict(sd)

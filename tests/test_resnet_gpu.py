@@ -53,6 +53,42 @@ def test_resnet_forward_bit_exact_vs_oracle_and_close_to_torch(n, split, monkeyp
 
 
 @pytest.mark.parametrize("split", SPLIT_MODES)
+def test_real_checkpoint_values_engine_equals_oracle_equals_build_torch(split, monkeypatch):
+    """The VALUES of one of the reference's 20 historical ResidualBlock checkpoints (tests/golden/resnet_ckpt_5.npz, captured by
+    a weights-only load) through the engine: logits / P / value bit for bit the oracle's, within 1e-5 / 1e-6 / 5e-6 of the
+    build's torch module (outputs recorded in the fixture), and complete self-play games with these weights bit-exact
+    against the oracle.  Parity against the reference itself: unpinned (no forward upstream)."""
+    from tests.util import load
+    monkeypatch.setenv("AZ_SPLIT_MAX", split)
+    z = load("resnet_ckpt_5.npz")
+    sd = {k[3:]: z[k] for k in z.files if k.startswith("w__")}
+    n, k, S, G = int(z["n"]), 4, 60, 5
+    e = az.Engine(n, k, S, 4, model="resnet", log_table=orc.numpy_log_table(S))
+    e.load_weights(sd, 0)
+    onet = orc.Net(n, resnet_tensors=fold_resnet_state_dict(sd))
+    o = orc.Oracle(n, k, S)
+    logits, P, v = e.net_eval(z["boards"], z["players"], z["lasts"])
+    for i in range(len(z["players"])):
+        ol, oP, ov = onet.eval(o.encode(z["boards"][i], int(z["players"][i]), int(z["lasts"][i])))
+        assert np.array_equal(logits[i], ol) and np.array_equal(P[i], oP) and v[i] == np.float32(ov)
+    np.testing.assert_allclose(logits, z["logits"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(P, z["P"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(v, z["value"], rtol=0, atol=5e-6)
+    e.selfplay(G, seed0=4100)
+    rec = e.records(); nply, res = e.games()
+    off = 0
+    for g in range(G):
+        noise, us = orc.selfplay_tape(4100 + g, n)
+        r = o.selfplay_game(onet, noise, us)
+        L = int(nply[g]); sl = slice(off, off + L)
+        assert L == r["nply"] and int(res[g]) == r["result"]
+        for key in ("actions", "visits", "pis", "z"):
+            assert np.array_equal(rec[key][sl], r[key]), f"game {g}: {key}"
+        off += L
+    e.close()
+
+
+@pytest.mark.parametrize("split", SPLIT_MODES)
 @pytest.mark.parametrize("n,k,S,G,cut", [(5, 4, 40, 5, 0), (9, 5, 24, 4, 5), (15, 5, 16, 3, 3)])
 def test_resnet_selfplay_bit_exact_vs_oracle(n, k, S, G, cut, split, monkeypatch):
     monkeypatch.setenv("AZ_SPLIT_MAX", split)

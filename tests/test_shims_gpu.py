@@ -200,6 +200,20 @@ def test_training_loop_plumbing_config1(device_replay):
         assert h["total"] == 6 and 0.0 <= h["win_rate"] <= 1.0 and h["wins"] + h["losses"] + h["draws"] == 6
 
 
+def test_training_loop_config0_at_its_stated_size():
+    """BASELINE.json configs[0] as the reference runs it (train.py:62-119 with constants.py's defaults): 5x5 / 4-in-a-row,
+    20 episodes of 100 self-play games at 100 simulations, 10 batches x 3 epochs of AdamW and a 51-game arena per episode,
+    promotion at a win rate above 0.55 -- about 12 s on one MI355X (the reference's README quotes half an hour on a laptop)."""
+    from alphazero_piskvorky_amd import train
+    hist = train.run(episodes=20, games=100, sims=100, eval_games=constants.EVALUATION_GAMES, eval_sims=constants.NUM_EVAL_SIMULATIONS, device="cuda:0", seed=11,
+                     log=lambda *_: None)
+    assert len(hist) == 20 and constants.EVALUATION_GAMES == 51
+    for h in hist:
+        assert h["examples"] >= 100 * 7 * 4 and h["examples"] % 4 == 0 and np.isfinite(h["loss"])
+        assert h["total"] == 51 and h["wins"] + h["losses"] + h["draws"] == 51
+        assert h["promoted"] == (h["win_rate"] > train.PROMOTION_THRESHOLD)
+
+
 def test_device_replay_ring_matches_host_examples():
     """sampling from the device ring gives exactly the examples generate_self_play would have produced."""
     from alphazero_piskvorky_amd import Engine, parallel
