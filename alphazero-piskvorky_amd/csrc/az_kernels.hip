@@ -44,6 +44,16 @@ void trunk_split(const LaunchCtx &c, int net_id)
         const int ngroups = (c.dv.B + G::G - 1) / G::G;
         dim3 bt(G::NW * 64);
         const ResWeights &w = c.rw[net_id];
+        if (g_tile_split) {    // by cell tiles: six launches of 4-wave workgroups (az_net.h k_tile_res)
+            const dim3 gt(ngroups, G::MT), b4(256);
+            hipLaunchKernelGGL((k_tile_res<N, 0>), gt, b4, 0, c.stream, c.dv, w.stem, w.stemb, w.blk[0], w.blkb[0], net_id, c.scratch, c.feat);
+            hipLaunchKernelGGL((k_tile_res<N, 1>), gt, b4, 0, c.stream, c.dv, w.blk[1], w.blkb[1], nullptr, nullptr, net_id, c.scratch, c.feat);
+            hipLaunchKernelGGL((k_tile_res<N, 2>), gt, b4, 0, c.stream, c.dv, w.blk[2], w.blkb[2], nullptr, nullptr, net_id, c.scratch, c.feat);
+            hipLaunchKernelGGL((k_tile_res<N, 1>), gt, b4, 0, c.stream, c.dv, w.blk[3], w.blkb[3], nullptr, nullptr, net_id, c.scratch, c.feat);
+            hipLaunchKernelGGL((k_tile_res<N, 2>), gt, b4, 0, c.stream, c.dv, w.blk[4], w.blkb[4], nullptr, nullptr, net_id, c.scratch, c.feat);
+            hipLaunchKernelGGL((k_tile_res<N, 3>), gt, b4, 0, c.stream, c.dv, w.blk[5], w.blkb[5], w.hd, w.hdb, net_id, c.scratch, c.feat);
+            return;
+        }
         hipLaunchKernelGGL((k_split_res<N, 0>), dim3(ngroups, 4), bt, 0, c.stream, c.dv, w.stem, w.stemb, net_id, c.scratch, c.feat);
         for (int blk = 0; blk < 3; blk++) {
             hipLaunchKernelGGL((k_split_res<N, 1>), dim3(ngroups, 4), bt, 0, c.stream, c.dv, w.blk[2 * blk], w.blkb[2 * blk], net_id, c.scratch, c.feat);

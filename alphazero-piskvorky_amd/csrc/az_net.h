@@ -15,7 +15,12 @@
 
 #ifdef AZ_STAMPS
 // diagnostic build only: per-workgroup phase time stamps (s_memtime) into a buffer no other code reads
-#define AZ_STAMP(k) do { if (threadIdx.x == 0 && dbg) dbg[(size_t)grp * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+// slots 0..5: s_memtime (shader clock ticks) at the phase boundaries; slots 14 / 15: s_memrealtime (the constant 100 MHz counter)
+// at the first and the last stamp, so that the clock the chip HELD inside the kernel is (t5 - t0) / (rt5 - rt0) x 100 MHz
+// (MI355X_MICROARCH.md, DVFS give-back item 6)
+#define AZ_STAMP(k) do { if (threadIdx.x == 0 && dbg) { dbg[(size_t)grp * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+    if ((k) == 0) dbg[(size_t)grp * 16 + 14] = __builtin_amdgcn_s_memrealtime(); \
+    if ((k) == 5) dbg[(size_t)grp * 16 + 15] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define AZ_STAMP(k) do { } while (0)
 #endif
@@ -131,7 +136,8 @@ __device__ __forceinline__ int pk_index(int ci, int pos)
 {
     return ((((ci >> 4) * 4 + (ci & 3)) * GEO::CS + pos) << 2) + ((ci >> 2) & 3);
 }
-enum { CONV_OUT_PACKED = 0, CONV_OUT3 = 1, CONV_OUT_RESIDUAL = 2 };   // RESIDUAL: relu(acc + bias + out[same index]) in place
+enum { CONV_OUT_PACKED = 0, CONV_OUT3 = 1, CONV_OUT_RESIDUAL = 2,    // RESIDUAL: relu(acc + bias + out[same index]) in place
+       CONV_OUT3_RESIDUAL = 3 };   // relu(acc + bias + res[packed index]) into the [co][cell] tile (the last block of a tile-split ResidualBlock trunk)
 
 // One conv layer on the workgroup's LDS image, computed as D[co][cell] = sum_k W[co][k] * X[k][cell]:
 // the weight fragment is the MFMA A operand (row = output channel), the activation fragment the B operand
@@ -150,9 +156,9 @@ template <class G, int CIN, int COUT, int MODE, int NTL = COUT / 16, int MTL = G
 __device__ __forceinline__ void conv_layer(const float *in, float *out, const float *__restrict__ wp,
                                            const float *__restrict__ bias, const unsigned short *wpos,
                                            const unsigned short *cellof, int wave, int lane, int nt_base = 0,
-                                           int mt_base = 0, int mt_cnt = MTL, int out_pos_off = 0)
+                                           int mt_base = 0, int mt_cnt = MTL, int out_pos_off = 0, const float *res = nullptr)
 {
-    constexpr bool OUT3 = MODE == CONV_OUT3;
+    constexpr bool OUT3 = MODE == CONV_OUT3 || MODE == CONV_OUT3_RESIDUAL;
     constexpr bool SUBSET = MTL < G::MT;                       // a tile-split kernel: waves without a tile skip the layer
     constexpr int NT = NTL;                                    // channel tiles handled by this workgroup
     constexpr int NTW = (AZ_NTW <= NT) ? AZ_NTW : NT;          // channel tiles per wave
@@ -287,7 +293,10 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
                     const int co = nt * 16 + q * 4 + rg;      // = 16*cg + 4*e + q' with cg = nt, e = q, q' = rg
                     float v = acc[t][i][rg] + bco[rg];
                     v = v > 0.0f ? v : 0.0f;
-                    if constexpr (OUT3) out[co * O3S + mt * 16 + r16 + (SUBSET ? 0 : mt_base * 16)] = v;
+                    if constexpr (MODE == CONV_OUT3_RESIDUAL) {
+                        float r = acc[t][i][rg] + bco[rg] + (valid ? res[pk_index<GO>(co, pos)] : 0.0f);
+                        out[co * O3S + mt * 16 + r16 + (SUBSET ? 0 : mt_base * 16)] = r > 0.0f ? r : 0.0f;
+                    } else if constexpr (OUT3) out[co * O3S + mt * 16 + r16 + (SUBSET ? 0 : mt_base * 16)] = v;
                     else if constexpr (MODE == CONV_OUT_RESIDUAL) {
                         if (valid) {                          // net block: relu(bn2(conv2(h)) + x), x updated in place
                             const int oi = pk_index<GO>(co, pos);
@@ -628,10 +637,9 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_split(DevState d, NetWeights w, 
 // the same k-ordered fma chain as in k_trunk -- which workgroup computes it does not enter -- so the results are
 // bit-identical (every parity test runs on this path too).
 // ------------------------------------------------------------------------------------------------
-template <int N>
-struct TileGeo {
-    typedef NetGeo<N> F;
-    static constexpr int PW = F::PW, PP = F::PP, MT = F::MT, nn = F::nn, M = F::M;
+template <class F, int NWT>
+struct TileGeoT {
+    static constexpr int N = F::n, PW = F::PW, PP = F::PP, MT = F::MT, nn = F::nn, M = F::M;
     // padded-image position of tile lane m (the centre of its 3x3 window), -1 for a lane without a cell to compute
     __host__ __device__ static constexpr int centre(int m)
     {
@@ -655,7 +663,7 @@ struct TileGeo {
         for (int i = 0; i < 16; i++) { const int c = centre(16 * t + i); if (c > v) v = c; }
         return v;
     }
-    // conv1 tiles stage A computes for tile t: every tile with a cell next to a cell of t (same board group)
+    // first-conv tiles stage A computes for tile t: every tile with a cell next to a cell of t (same board group)
     __host__ __device__ static constexpr int c1_lo(int t)
     {
         if (F::ROWT) return (t % N) > 0 ? t - 1 : t;
@@ -668,7 +676,7 @@ struct TileGeo {
         const int b = (16 * t + 15 + N + 1) >> 4;
         return b > MT - 1 ? MT - 1 : b;
     }
-    // origins (first padded-image position held in LDS) and extents of the two stages' images
+    // origins (first padded-image position held in LDS) and extents of the two kinds of image
     __host__ __device__ static constexpr int org_b(int t) { return lo_of(t) - (PW + 1); }
     __host__ __device__ static constexpr int org_a(int t) { return lo_of(c1_lo(t)) - (PW + 1); }
     __host__ __device__ static constexpr int span_b()
@@ -691,11 +699,76 @@ struct TileGeo {
     }
     static constexpr int CSA = ((span_a() + 15) / 16) * 16, CSB = ((span_b() + 15) / 16) * 16;   // plane strides: multiples of 16 (conflict-free b128 reads)
     static constexpr int MTL1 = c1_tiles();
-    static_assert(MTL1 <= 4, "stage A covers conv1 with 8 waves = 2 channel tiles x 4 cell tiles");
+    static_assert(MTL1 <= 4, "stage A covers the first conv with at most 4 cell tiles per channel tile");
     // what conv_layer sees of the geometry in each stage: the full board's tiling, the local image's stride
-    struct A { static constexpr int NW = F::NW, MT = F::MT, PW = F::PW, CS = CSA, CS3 = 16; };
-    struct B { static constexpr int NW = F::NW, MT = F::MT, PW = F::PW, CS = CSB, CS3 = 16; };
-    static constexpr int LDSA = 36 * CSA, LDSB = 64 * CSB + 128 * 16;
+    struct A { static constexpr int NW = NWT, MT = F::MT, PW = F::PW, CS = CSA, CS3 = 16; };
+    struct B { static constexpr int NW = NWT, MT = F::MT, PW = F::PW, CS = CSB, CS3 = 16; };
+
+    // relative-position tables of one workgroup (origin org, image stride csl) + the group's activity flag; false = nothing to do
+    __device__ static __forceinline__ bool prologue(const DevState &d, int net_id, int b0, int org, int csl, unsigned short *wpos,
+                                                    unsigned short *cellof, int *any_active, int tid, int nth)
+    {
+        if (tid == 0) *any_active = 0;
+        __syncthreads();
+        if (tid < F::G) {
+            const int b = b0 + tid;
+            if (b < d.B) {
+                const int kind = d.leaf_kind[b];
+                if ((kind == LEAF_ROOT || kind == LEAF_EXPAND) && d.s_status[b] == SLOT_ACTIVE && d.s_net[b] == net_id)
+                    atomicOr(any_active, 1);
+            }
+        }
+        for (int m = tid; m < F::MR; m += nth) {
+            const int c = centre(m);
+            int cell = 0xFFFF;
+            if (c >= 0) {
+                if constexpr (F::ROWT) { if ((m & 15) < N) cell = (m >> 4) * N + (m & 15); }
+                else cell = m;
+            }
+            const int rel = c - org;
+            // lanes outside this workgroup's image (other tiles, junk lanes) get a harmless in-range position: they are
+            // either never used or computed and thrown away
+            wpos[m] = (unsigned short)((c >= 0 && rel >= PW + 1 && rel + PW + 1 < csl) ? rel : PW + 1);
+            cellof[m] = (unsigned short)cell;
+        }
+        __syncthreads();
+        return *any_active != 0;
+    }
+    // games.py:86-129 encode of the cells inside an image of stride csl starting at org: planes [mover | opponent | last move | 0]
+    __device__ static __forceinline__ void encode(const DevState &d, int b0, int org, int csl, float *planes, const unsigned short *cellof,
+                                                  int tid, int nth)
+    {
+        for (int m = tid; m < F::MR; m += nth) {
+            const int cell = cellof[m];
+            const int rel = centre(m) - org;
+            if (cell != 0xFFFF && rel >= 0 && rel < csl) {
+                const int g = cell / nn, p = cell - g * nn;
+                const int b = b0 + g;
+                if (b < d.B) {
+                    const u64 *lf = d.leaf + (size_t)b * 8;
+                    const int ps = sym_cell(d.leaf_sym, b, p, N);
+                    if ((lf[ps >> 6] >> (ps & 63)) & 1ull) planes[rel] = 1.0f;
+                    if ((lf[4 + (ps >> 6)] >> (ps & 63)) & 1ull) planes[csl + rel] = 1.0f;
+                    if (d.leaf_last[b] == ps) planes[2 * csl + rel] = 1.0f;
+                }
+            }
+        }
+    }
+    // the positions org .. org + CSB of the 16 planes (cg, q) of a packed 64-channel board image (stride F::CS) into LDS
+    __device__ static __forceinline__ void load_rows(const float *img, int org, float *lds, int tid, int nth)
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(img);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = tid; i < 16 * CSB; i += nth) {
+            const int plane = i / CSB, rel = i - plane * CSB, pos = org + rel;
+            dst[i] = (pos >= 0 && pos < F::CS) ? src[plane * F::CS + pos] : float4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+};
+template <int N>
+struct TileGeo : TileGeoT<NetGeo<N>, AZ_NW> {
+    typedef TileGeoT<NetGeo<N>, AZ_NW> T;
+    static constexpr int LDSA = 36 * T::CSA, LDSB = 64 * T::CSB + 128 * 16;
 };
 
 template <int N, int STAGE>
@@ -713,68 +786,23 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_tile(DevState d, NetWeights w, i
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = blockIdx.x, t = blockIdx.y, b0 = grp * F::G;
-    if (tid == 0) any_active = 0;
-    __syncthreads();
-    if (tid < F::G) {
-        const int b = b0 + tid;
-        if (b < d.B) {
-            const int kind = d.leaf_kind[b];
-            if ((kind == LEAF_ROOT || kind == LEAF_EXPAND) && d.s_status[b] == SLOT_ACTIVE && d.s_net[b] == net_id)
-                atomicOr(&any_active, 1);
-        }
-    }
     const int org = STAGE == 1 ? TG::org_a(t) : TG::org_b(t);
-    constexpr int CSL = STAGE == 1 ? TG::CSA : TG::CSB;
-    for (int m = tid; m < F::MR; m += NTH) {
-        const int c = TG::centre(m);
-        int cell = 0xFFFF;
-        if (c >= 0) {
-            if constexpr (F::ROWT) { if ((m & 15) < N) cell = (m >> 4) * N + (m & 15); }
-            else cell = m;
-        }
-        const int rel = c - org;
-        // lanes outside this workgroup's image (other tiles, junk lanes) get a harmless in-range position: they are either
-        // never used or computed and thrown away
-        wpos[m] = (unsigned short)((c >= 0 && rel >= TG::PW + 1 && rel + TG::PW + 1 < CSL) ? rel : TG::PW + 1);
-        cellof[m] = (unsigned short)cell;
-    }
     if constexpr (STAGE == 1) {
         float4 *z = reinterpret_cast<float4 *>(lds);
         for (int i = tid; i < TG::LDSA / 4; i += NTH) z[i] = float4{0.f, 0.f, 0.f, 0.f};
     }
-    __syncthreads();
-    if (!any_active) return;
+    if (!TG::prologue(d, net_id, b0, org, STAGE == 1 ? TG::CSA : TG::CSB, wpos, cellof, &any_active, tid, NTH)) return;
     float *img2 = scratch + (size_t)grp * SG::PER_GROUP + SG::IMG1;      // the packed 64-channel board image (padding ring zeroed once)
     if constexpr (STAGE == 1) {
         float *planes = lds, *img1 = lds + 4 * TG::CSA;
-        for (int m = tid; m < F::MR; m += NTH) {              // games.py:86-129 encode, the cells inside this image
-            const int cell = cellof[m];
-            const int rel = TG::centre(m) - org;
-            if (cell != 0xFFFF && rel >= 0 && rel < TG::CSA) {
-                const int g = cell / F::nn, p = cell - g * F::nn;
-                const int b = b0 + g;
-                if (b < d.B) {
-                    const u64 *lf = d.leaf + (size_t)b * 8;
-                    const int ps = sym_cell(d.leaf_sym, b, p, N);
-                    if ((lf[ps >> 6] >> (ps & 63)) & 1ull) planes[rel] = 1.0f;
-                    if ((lf[4 + (ps >> 6)] >> (ps & 63)) & 1ull) planes[TG::CSA + rel] = 1.0f;
-                    if (d.leaf_last[b] == ps) planes[2 * TG::CSA + rel] = 1.0f;
-                }
-            }
-        }
+        TG::encode(d, b0, org, TG::CSA, planes, cellof, tid, NTH);
         __syncthreads();
         const int tlo = TG::c1_lo(t), cnt = TG::c1_hi(t) - tlo + 1;
         conv_layer<typename TG::A, 4, 32, CONV_OUT_PACKED, 2, TG::MTL1>(planes, img1, w.c1, w.c1b, wpos, cellof, wave, lane, 0, tlo, cnt);
         __syncthreads();
         conv_layer<typename TG::A, 32, 64, CONV_OUT_PACKED, 4, 1, F>(img1, img2, w.c2, w.c2b, wpos, cellof, wave, lane, 0, t, 1, org);
     } else {
-        // the rows of the conv2 image this tile's windows touch: plane (cg, q) of the board image, positions org .. org + CSB
-        const float4 *src = reinterpret_cast<const float4 *>(img2);
-        float4 *dst = reinterpret_cast<float4 *>(lds);
-        for (int i = tid; i < 16 * TG::CSB; i += NTH) {
-            const int plane = i / TG::CSB, rel = i - plane * TG::CSB, pos = org + rel;
-            dst[i] = (pos >= 0 && pos < F::CS) ? src[plane * F::CS + pos] : float4{0.f, 0.f, 0.f, 0.f};
-        }
+        TG::load_rows(img2, org, lds, tid, NTH);              // the rows of the conv2 image this tile's windows touch
         __syncthreads();
         float *out3 = lds + 64 * TG::CSB;                     // [co][16 cells of the tile]
         conv_layer<typename TG::B, 64, 128, CONV_OUT3, 8, 1, typename TG::B, 16>(lds, out3, w.c3, w.c3b, wpos, cellof, wave, lane, 0, t, 1);
@@ -1059,6 +1087,103 @@ __global__ __launch_bounds__(ResGeo<N>::NW * 64) void k_split_res(DevState d, co
                             if (j < G::PC + G::VC) {
                                 float v = acc[rg] + hb[rg];
                                 feat[(size_t)b * G::FROW + j * G::nn + p] = v > 0.0f ? v : 0.0f;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Tile-split trunk of the ResidualBlock variant: like k_tile, a board spread by CELL tiles, 4 waves per workgroup (the four
+// 16-channel tiles of a 64-channel conv on one 16-cell tile: 144 dependent MFMAs each), grid (groups, MT).  Six launches
+// instead of k_split_res's eight:
+//   KIND 0  encode + stem on the tiles around t (recomputed per workgroup: 9 k-steps) -> x of tile t to image A; res1.conv1 on tile t -> image B
+//   KIND 1  rows of B around t -> conv2 of a block on tile t, relu(. + x) with x read and written in place in A
+//   KIND 2  rows of A around t -> conv1 of the next block on tile t -> B
+//   KIND 3  the last conv2: relu(. + x) stays in LDS as [channel][16 cells] -> 1x1 heads of the tile -> feature rows
+// Same fma chains as k_trunk_res: bit-identical.
+template <int N>
+struct ResTileGeo : TileGeoT<ResGeo<N>, 4> {
+    typedef TileGeoT<ResGeo<N>, 4> T;
+    static constexpr int LDS0 = 68 * T::CSA, LDSC = 64 * T::CSB + 64 * 16;
+};
+
+template <int N, int KIND>
+__global__ __launch_bounds__(256) void k_tile_res(DevState d, const float *__restrict__ wp, const float *__restrict__ bias,
+                                                  const float *__restrict__ wp2, const float *__restrict__ bias2, int net_id,
+                                                  float *__restrict__ scratch, float *__restrict__ feat)
+{
+    typedef ResGeo<N> F;
+    typedef ResTileGeo<N> TG;
+    constexpr int NTH = 256;
+    __shared__ __attribute__((aligned(16))) float lds[KIND == 0 ? TG::LDS0 : TG::LDSC];
+    __shared__ unsigned short wpos[F::MR];
+    __shared__ unsigned short cellof[F::MR];
+    __shared__ int any_active;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = blockIdx.x, t = blockIdx.y, b0 = grp * F::G;
+    const int org = KIND == 0 ? TG::org_a(t) : TG::org_b(t);
+    if constexpr (KIND == 0) {
+        float4 *z = reinterpret_cast<float4 *>(lds);
+        for (int i = tid; i < TG::LDS0 / 4; i += NTH) z[i] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (!TG::prologue(d, net_id, b0, org, KIND == 0 ? TG::CSA : TG::CSB, wpos, cellof, &any_active, tid, NTH)) return;
+    float *A = scratch + (size_t)grp * ResSplitGeo<N>::PER_GROUP, *B = A + ResSplitGeo<N>::IMG;
+    if constexpr (KIND == 0) {
+        float *planes = lds, *x = lds + 4 * TG::CSA;          // x: the stem's output around tile t, packed, local geometry
+        TG::encode(d, b0, org, TG::CSA, planes, cellof, tid, NTH);
+        __syncthreads();
+        const int tlo = TG::c1_lo(t), cnt = TG::c1_hi(t) - tlo + 1;
+        conv_layer<typename TG::A, 4, 64, CONV_OUT_PACKED, 4, TG::MTL1>(planes, x, wp, bias, wpos, cellof, wave, lane, 0, tlo, cnt);
+        __syncthreads();
+        // x of tile t also goes to the board image A: the skip operand of res1 (read in place by KIND 1)
+        for (int i = tid; i < 64 * 16; i += NTH) {
+            const int co = i >> 4, m = t * 16 + (i & 15);
+            if (cellof[m] != 0xFFFFu) {
+                const int rel = wpos[m];
+                A[pk_index<F>(co, rel + org)] = x[pk_index<typename TG::A>(co, rel)];
+            }
+        }
+        conv_layer<typename TG::A, 64, 64, CONV_OUT_PACKED, 4, 1, F>(x, B, wp2, bias2, wpos, cellof, wave, lane, 0, t, 1, org);
+    } else {
+        TG::load_rows(KIND == 2 ? A : B, org, lds, tid, NTH);
+        __syncthreads();
+        if constexpr (KIND == 1) conv_layer<typename TG::B, 64, 64, CONV_OUT_RESIDUAL, 4, 1, F>(lds, A, wp, bias, wpos, cellof, wave, lane, 0, t, 1, org);
+        else if constexpr (KIND == 2) conv_layer<typename TG::B, 64, 64, CONV_OUT_PACKED, 4, 1, F>(lds, B, wp, bias, wpos, cellof, wave, lane, 0, t, 1, org);
+        else {
+            float *xt = lds + 64 * TG::CSB;                   // [channel][16 cells of the tile]: the trunk's output
+            conv_layer<typename TG::B, 64, 64, CONV_OUT3_RESIDUAL, 4, 1, F, 16>(lds, xt, wp, bias, wpos, cellof, wave, lane, 0, t, 1, org, A);
+            __syncthreads();
+            if (wave == 0) {                                  // policy_conv (64->2) and value_conv (64->1), BatchNorm folded: wp2 = packed head rows, bias2[3]
+                const int q = lane >> 4, r16 = lane & 15;
+                const float4 *wp4 = reinterpret_cast<const float4 *>(wp2) + lane;
+                float hb[4];
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) hb[rg] = (q * 4 + rg) < (F::PC + F::VC) ? bias2[q * 4 + rg] : 0.0f;
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float *ip = xt + q * 16 + r16;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) {
+                    const float4 bq = wp4[s4 * 64];
+                    acc = mfma4(bq.x, ip[(s4 * 16 + 0) * 16], acc);
+                    acc = mfma4(bq.y, ip[(s4 * 16 + 4) * 16], acc);
+                    acc = mfma4(bq.z, ip[(s4 * 16 + 8) * 16], acc);
+                    acc = mfma4(bq.w, ip[(s4 * 16 + 12) * 16], acc);
+                }
+                const int cell = cellof[t * 16 + r16];
+                if (cell != 0xFFFF) {
+                    const int g = cell / F::nn, p = cell - g * F::nn;
+                    const int b = b0 + g;
+                    if (b < d.B && d.s_net[b] == net_id) {
+#pragma unroll
+                        for (int rg = 0; rg < 4; rg++) {
+                            const int j = q * 4 + rg;     // 0-1 policy_conv, 2 value_conv
+                            if (j < F::PC + F::VC) {
+                                float v = acc[rg] + hb[rg];
+                                feat[(size_t)b * F::FROW + j * F::nn + p] = v > 0.0f ? v : 0.0f;
                             }
                         }
                     }

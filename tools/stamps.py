@@ -8,23 +8,37 @@ import alphazero_piskvorky_amd as az
 from alphazero_piskvorky_amd import _capi
 from alphazero_piskvorky_amd.weights import synthetic_state_dict
 n, B = int(sys.argv[1]) if len(sys.argv) > 1 else 15, 256      # one lane, one round of workgroups at n = 15
-e = az.Engine(n, 5 if n > 5 else 4, 8, B, engines=1)
+S = int(os.environ.get("AZ_STAMPS_SIMS", "400"))     # long plies: the >= 2 s of back-to-back launches before the reading end before the games do
+e = az.Engine(n, 5 if n > 5 else 4, S, B, engines=1)
 e.load_weights(synthetic_state_dict(n), 0)
 if len(sys.argv) > 2:
     e.set_trunk_mode(sys.argv[2])
 e.selfplay_begin(B, seed0=1)
-e.selfplay_step(1)
+import time
+t_end = time.time() + float(os.environ.get("AZ_STAMPS_WARM_SECONDS", "2.2"))     # the guide asks for >= 2 s of back-to-back launches before the reading
+while time.time() < t_end:
+    e.selfplay_step(1)
 G = {15: 1, 9: 2, 5: 4}[n]
 ng = (B + G - 1) // G
 buf = np.zeros((ng, 16), np.uint64)
 rc = _capi.lib().az_debug_stamps(e.h, buf.ctypes.data_as(C.c_void_p), ng)
 assert rc == 0, rc
 t = buf[:, :6].astype(np.int64)
+rt = buf[:, 14:16].astype(np.int64)
+# workgroups whose game has ended keep the stamps of an older launch: keep the rows that are one launch's (monotonic, < 1 ms)
+ok = (np.diff(t, axis=1) > 0).all(axis=1) & (rt[:, 1] > rt[:, 0]) & (rt[:, 1] - rt[:, 0] < 100000)
+print("workgroups with a complete set of stamps from one launch:", int(ok.sum()), "of", ng)
+t, rt = t[ok], rt[ok]
+ng = int(ok.sum())
 d = np.diff(t, axis=1)
 names = ["prologue(zero+tables+encode)", "conv1", "conv2", "conv3(+out3 write)", "heads+feat"]
 print("workgroups", ng, "stamp units = s_memtime ticks (100 MHz constant clock on gfx9? check total)")
 for i, nm in enumerate(names):
     print(f"{nm:32s} mean {d[:, i].mean():10.1f}  min {d[:, i].min():8d}  max {d[:, i].max():8d}")
+if ng:
+    ghz = (t[:, 5] - t[:, 0]) / (rt[:, 1] - rt[:, 0]) * 0.1
+    print(f"in-kernel clock (d s_memtime / d s_memrealtime x 100 MHz): median {np.median(ghz):.3f} GHz, min {ghz.min():.3f}, max {ghz.max():.3f}; "
+          f"workgroup duration median {np.median(rt[:, 1] - rt[:, 0]) * 10:.0f} ns")
 tot = t[:, 5] - t[:, 0]
 print("total per WG mean", tot.mean(), " kernel span", t[:, 5].max() - t[:, 0].min())
 starts = np.sort(t[:, 0] - t[:, 0].min())
