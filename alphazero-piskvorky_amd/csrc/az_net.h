@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(256) void k_tile_res(DevState d, const float *__res
 // kernel costs is the number of CU slots it has to win and the times it stages a row's features (3 instead of 19);
 // measured in the 4-lane pipeline at 15x15: one tile per workgroup 158.4 ms per ply, <4, 1> 157.6, trunk-bound floor 155.1.
 template <class G, int TPW, int R>
-__global__ __launch_bounds__(TPW * 256) void k_fc(DevState d, NetWeights w, int net_id, const float *__restrict__ feat,
+__global__ __launch_bounds__(TPW * 256, (R > 1 && TPW <= 2) ? 2 * TPW : 1) void k_fc(DevState d, NetWeights w, int net_id, const float *__restrict__ feat,
                                                   unsigned long long *dbgfc)
 {
     constexpr int NTH = TPW * 256, TW = TPW * R;       // threads, tiles per workgroup
@@ -1301,25 +1301,24 @@ __global__ __launch_bounds__(TPW * 256) void k_fc(DevState d, NetWeights w, int 
     for (int rd = 0; rd < R; rd++) {
         const int tile = tile0 + rd * TPW;
         const bool has_tile = tile < tile_end;
-        float4 wn[G::QGMAX];                           // the next round's fragments fly while this round computes
-        if (R > 1) {
-            const int tn = tile + TPW < tile_end ? tile + TPW : tile_end - 1;
-            const float4 *wp4 = wbase + (size_t)(tn - tsub) * 4 * QG * 64;
-#pragma unroll
-            for (int j = 0; j < G::QGMAX; j++) wn[j] = (rd + 1 < R && j < QG) ? wp4[(size_t)j * 64] : float4{0.f, 0.f, 0.f, 0.f};
-        }
+        // the next round's fragments are requested into the registers of this round's as soon as those have been used: a
+        // whole round (4 QG MFMAs) of flight time, no second register set (two workgroups fit a CU: one stages while one computes)
+        const int tn = tile + TPW < tile_end ? tile + TPW : tile_end - 1;
+        const float4 *wnext = wbase + (size_t)(tn - tsub) * 4 * QG * 64;
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (has_tile) {
 #pragma unroll
-            for (int j = 0; j < G::QGMAX; j++)
-                if (j < QG) {
-                    const float4 af = fp[j * 64];
-                    acc = mfma4(af.x, wf[j].x, acc);
-                    acc = mfma4(af.y, wf[j].y, acc);
-                    acc = mfma4(af.z, wf[j].z, acc);
-                    acc = mfma4(af.w, wf[j].w, acc);
+        for (int j = 0; j < G::QGMAX; j++)
+            if (j < QG) {
+                const float4 af = fp[j * 64];
+                const float4 wv = wf[j];
+                if (R > 1 && rd + 1 < R) wf[j] = wnext[(size_t)j * 64];
+                if (has_tile) {
+                    acc = mfma4(af.x, wv.x, acc);
+                    acc = mfma4(af.y, wv.y, acc);
+                    acc = mfma4(af.z, wv.z, acc);
+                    acc = mfma4(af.w, wv.w, acc);
                 }
-        }
+            }
         float4 *pr = part + (rd & 1) * TPW * 3 * 64;
         if (chain) pr[(tl * 3 + chain - 1) * 64 + lane] = float4{acc[0], acc[1], acc[2], acc[3]};
         __syncthreads();
@@ -1343,10 +1342,6 @@ __global__ __launch_bounds__(TPW * 256) void k_fc(DevState d, NetWeights w, int 
                     }
                 }
             }
-        }
-        if (R > 1) {
-#pragma unroll
-            for (int j = 0; j < G::QGMAX; j++) wf[j] = wn[j];
         }
     }
     FC_STAMP(2);

@@ -51,6 +51,9 @@ def all_gather_packed(packed, count, record_bytes, dst=None, force=False):
     return [o[: c * record_bytes] for o, c in zip(outs, counts)], counts
 
 
+last_exchange = None      # which path the last gather_packed_records took: "az_dist" (RCCL inside the library) | "torch.distributed" | "local"
+
+
 def engine_comm(engine, device, force=False):
     """True when `engine` holds an RCCL communicator over the ranks of the current torch.distributed group, creating it on
     first use: rank 0 draws the unique id and the group carries its 128 bytes to everybody.  Only for "nccl" groups (a gloo
@@ -61,12 +64,31 @@ def engine_comm(engine, device, force=False):
     world, rank = td.get_world_size(), td.get_rank()
     if engine.dist_world() == world and getattr(engine, "_dist_group_ok", False):
         return True
-    from ._capi import AZ_DIST_ID_BYTES, dist_unique_id
-    idt = torch.zeros(AZ_DIST_ID_BYTES, dtype=torch.uint8, device=device)
+    if getattr(engine, "_dist_failed", False):
+        return False
+    from ._capi import AZ_DIST_ID_BYTES, AzError, dist_unique_id
+    # every rank learns whether EVERY rank could join (a rank that cannot load RCCL must not leave the others waiting in a
+    # collective): the id travels with a validity flag, and the outcome of az_dist_init is summed over the group
+    idt = torch.zeros(AZ_DIST_ID_BYTES + 1, dtype=torch.uint8, device=device)
     if rank == 0:
-        idt.copy_(torch.frombuffer(bytearray(dist_unique_id()), dtype=torch.uint8))
+        try:
+            idt[:AZ_DIST_ID_BYTES].copy_(torch.frombuffer(bytearray(dist_unique_id()), dtype=torch.uint8))
+            idt[AZ_DIST_ID_BYTES] = 1
+        except AzError:
+            pass
     td.broadcast(idt, 0)
-    engine.dist_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+    host = idt.cpu().numpy()
+    ok = int(host[AZ_DIST_ID_BYTES]) == 1
+    if ok:
+        try:
+            engine.dist_init(host[:AZ_DIST_ID_BYTES].tobytes(), rank, world)
+        except AzError:
+            ok = False
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=device)
+    td.all_reduce(flag)
+    if int(flag.item()) != world:
+        engine._dist_failed = True        # fall back to torch.distributed's collectives (the same RCCL underneath)
+        return False
     engine._dist_group_ok = True
     return True
 
@@ -75,14 +97,17 @@ def gather_packed_records(engine, device, dst=None, force=False):
     """Pack this rank's episode records on the device and exchange them.  Returns (uint8 tensor of all records
     in rank order -- empty on the ranks a gather-to-root leaves out --, per-rank counts)."""
     import torch.distributed as td
+    global last_exchange
     if engine_comm(engine, device, force):
         # the library's own exchange: true sizes, only to the ranks that asked
+        last_exchange = "az_dist"
         counts = engine.dist_counts()
         receive = dst is None or dst == engine.dist_rank()
         total = sum(counts) if receive else 0
         out = torch.empty(max(total, 1) * engine.record_bytes, dtype=torch.uint8, device=device)
         engine.dist_gather_records(-1 if dst is None else int(dst), out.data_ptr() if receive else 0)
         return out[: total * engine.record_bytes], counts
+    last_exchange = "torch.distributed" if _dist_on(force) else "local"
     count = engine.last_records
     packed = torch.zeros(max(count, 1) * engine.record_bytes, dtype=torch.uint8, device=device)
     if count:

@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--trunk", default="f32", choices=["f32", "bf16x3", "f16x2"], help="f32 = the canonical float32 conv trunk (bit-exact against the oracle, the "
                     "headline); bf16x3 / f16x2 = opt-in fp32-emulating trunks on the 16-bit matrix cores (tolerance instead of bit-exactness)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-emul", action="store_true", help="skip the short runs of the two opt-in fp32-emulating trunks that the default f32 line reports beside itself")
     ap.add_argument("--pmc-run", action="store_true", help="counter-collection run: 8 sims per move so the pass stays short")
     a = ap.parse_args()
     if a.gpus < 1:
@@ -272,7 +273,8 @@ def main():
                            "finished games stay empty until the longest game ends",
                    "games": int(g_all), "seconds": ep_s, "games_per_sec": g_all / ep_s,
                    "node_expansions_per_sec": e_all / ep_s, "mean_plies_per_game": p_all / g_all,
-                   "record_gather_seconds": tg_s, "records_gathered": int(sum(counts)), "tape_wait_seconds": tw_s}
+                   "record_gather_seconds": tg_s, "records_gathered": int(sum(counts)), "record_exchange": parallel.last_exchange,
+                   "tape_wait_seconds": tw_s}
         # ---- steady state: games >> slots, every freed slot takes the next game of the engine's shared queue ----
         sg = a.steady_games if a.steady_games >= 0 else 3 * B
         if sg > 0:
@@ -290,6 +292,31 @@ def main():
                                        "tape_wait_seconds": float(st[1].item())}
 
     persist = eng.persistent()
+    # ---- beside the headline (never instead of it): the same shard on the two opt-in fp32-emulating trunks, a few plies each ----
+    emul = None
+    if a.trunk == "f32" and world == 1 and not a.no_emul and not a.pmc_run:
+        emul = {}
+        for mode in ("bf16x3", "f16x2"):
+            try:
+                eng.set_trunk_mode(mode)
+                eng.selfplay_begin(B, seed0=1_000_000 + rank * B)
+                eng.selfplay_step(max(a.warmup, 1))
+                torch.cuda.synchronize()
+                _, e0 = eng.selfplay_step(0)
+                te = time.perf_counter()
+                _, e1 = eng.selfplay_step(min(a.steps, 6))
+                torch.cuda.synchronize()
+                de = time.perf_counter() - te
+                eng.selfplay_end()
+                ex = (e1["expansions"] - e0["expansions"]) + (e1["plies"] - e0["plies"])
+                emul[mode] = {"node_expansions_per_sec": ex / de, "ms_per_step": de * 1e3 / min(a.steps, 6), "steps": min(a.steps, 6),
+                              "dtype": f"{mode}: float32 emulated on the 16-bit matrix cores by split operands, float32 accumulate -- opt-in, a tolerance "
+                                       "instead of bit-exactness (tests/test_emulated_trunk_gpu.py: within 2e-5 / 1e-6 / 2e-6 of the reference's torch "
+                                       "logits / P / value, the reference's visit counts on all 120 recorded plies)"}
+            except Exception as ex_:          # e.g. weights outside float16's range
+                emul[mode] = {"error": str(ex_)}
+        eng.set_trunk_mode("f32")
+
     if rank == 0:
         trunk_f, fc_f = net_flops(n, a.model)
         boards = cal["expansions"] + cal["plies"]        # boards the trunk kernel evaluated in the calibration ply
@@ -362,6 +389,7 @@ def main():
             "self_play_games_per_sec": None if episode is None else episode["games_per_sec"],
             "self_play_games_per_sec_steady_state": None if episode is None or "steady_state" not in episode else episode["steady_state"]["games_per_sec"],
             "episode": episode,
+            "opt_in_emulated_trunks": emul,
             "roofline": {"kernel": (f"k_search<{n},{persist}> (persistent: one launch per ply = {S + 1} x [encode+conv trunk+heads (MFMA), FC layers, tree step], "
                                     f"{persist} games per workgroup, trees in LDS; priced with the trunk FLOPs only)" if persist
                                     else f"k_trunk_res_emul<{n}, {a.trunk}> (encode+stem+3 residual blocks+head convs, LDS-resident; the 64->64 convs = {6 if a.trunk == 'bf16x3' else 3} x v_mfma_f32_16x16x32_{'bf16' if a.trunk == 'bf16x3' else 'f16'} per tile and 32 k; peak = 16-bit dense peak / {6 if a.trunk == 'bf16x3' else 3})" if a.trunk != "f32" and a.model == "resnet"

@@ -17,8 +17,15 @@ while active > 0:
 tot = time.perf_counter() - t0
 rows = np.array(rows)
 print("plies", len(rows), "total", round(tot, 2), "s")
+full = np.median(rows[rows[:, 0] == rows[0, 0], 1])          # ply time with every slot busy
+print(f"full-occupancy ply {1e3 * full:.1f} ms; a ply with a active games costs a / {int(rows[0, 0])} of that at the throughput rate")
 for lo, hi in ((513, 1024), (129, 512), (33, 128), (9, 32), (1, 8)):
     m = (rows[:, 0] >= lo) & (rows[:, 0] <= hi)
     if m.any():
-        print(f"active {lo:4d}-{hi:4d}: plies {m.sum():4d}  time {rows[m, 1].sum():6.2f} s  mean ms/ply {1e3 * rows[m, 1].mean():7.1f}")
+        ideal = (rows[m, 0] / rows[0, 0] * full).sum()
+        print(f"active {lo:4d}-{hi:4d}: plies {m.sum():4d}  time {rows[m, 1].sum():6.2f} s  mean ms/ply {1e3 * rows[m, 1].mean():7.1f}"
+              f"  at the throughput rate {ideal:5.2f} s  (x{rows[m, 1].sum() / ideal:.2f})")
+if len(sys.argv) > 2:
+    for a, t in rows:
+        print(int(a), round(1e3 * t, 2))
 eng.selfplay_end(); eng.close()
