@@ -47,7 +47,8 @@ struct GameLds {
 };
 
 // the tree step of one game on LDS rows: k_step's two stages (az_tree.h) with the node array, the path and the evaluator
-// outputs in LDS.  One wavefront.  No subtree reuse, no evaluation cache on this path.
+// outputs in LDS.  One wavefront.  No subtree reuse on this path; an evaluation-cache hit (LEAF_*_HIT, set by k_search before the
+// net phase) is consumed exactly like the evaluation it stands for.
 template <int N, class PG, bool SYNTH>
 __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edge *rows, unsigned *path, GameLds &gs,
                                          const float *lg, const float *hid, const double *sq_lds, int rootN, int do_select,
@@ -56,7 +57,8 @@ __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edg
 {
     typedef TreeGeo<N> G;
     static_assert(G::CPL == 1, "the LDS tree is for boards of at most 64 cells");
-    const int kind = gs.leaf_kind, depth0 = gs.depth, rows0 = gs.rows_used, leaf_last = gs.leaf_last;
+    const int kind_raw = gs.leaf_kind, depth0 = gs.depth, rows0 = gs.rows_used, leaf_last = gs.leaf_last;
+    const int kind = kind_raw == LEAF_EXPAND_HIT ? LEAF_EXPAND : (kind_raw == LEAF_ROOT_HIT ? LEAF_ROOT : kind_raw);
     Plane lme, lopp;
 #pragma unroll
     for (int q = 0; q < 4; q++) { lme.w[q] = gs.leaf[q]; lopp.w[q] = gs.leaf[4 + q]; }
@@ -296,12 +298,33 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
     __syncthreads();
     if (mine && lane == 0 && netid) atomicOr(&wg_net, 1);          // a workgroup's games share one net (arena: GP = 1)
     unsigned long long cnt[4] = {0ull, 0ull, 0ull, 0ull};
+    unsigned long long cache_lookups = 0ull, cache_hits = 0ull;
     float *inA = lds, *inB = lds + 32 * PG::CS;
 
     for (int idx = 0; idx <= S; idx++) {
         if (tid == 0) any_eval = 0;
         __syncthreads();
         if (!SYNTH) {
+            // opt-in evaluation cache (az_set_eval_cache): the game's wave looks its pending leaf up in the table in HBM; a hit
+            // puts the net's outputs for it into the LDS rows and the iteration needs no net for this game -- none at all when
+            // every game of the workgroup hits
+            if (d.cache && mine && leaf_needs_net(games[wave].leaf_kind)) {
+                GameLds &gs = games[wave];
+                Plane lme, lopp;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { lme.w[q] = gs.leaf[q]; lopp.w[q] = gs.leaf[4 + q]; }
+                float cx[TG::CPL], ch;
+                const bool hit = cache_lookup<N>(d, lme, lopp, gs.leaf_last, netid, lane, cx, ch);
+                if (hit) {
+#pragma unroll
+                    for (int i = 0; i < TG::CPL; i++) logits_l[wave * PG::RW + lane + 64 * i] = cx[i];
+                    vhid_l[wave * 64 + lane] = ch;
+                    if (lane == 0) gs.leaf_kind = gs.leaf_kind == LEAF_ROOT ? LEAF_ROOT_HIT : LEAF_EXPAND_HIT;
+                }
+                cache_lookups += 1ull;
+                cache_hits += hit ? 1ull : 0ull;
+            }
+            __syncthreads();
             if (tid < GP && leaf_needs_net(games[tid].leaf_kind)) atomicOr(&any_eval, 1);
             __syncthreads();
         }
@@ -376,6 +399,17 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
             __syncthreads();
             if (!(AZ_SEARCH_SKIP & 1)) fc_mfma<PG, NG>(w, featl, logits_l, vhid_l, wave, lane);
             __syncthreads();
+            // a fresh evaluation is remembered (a game that hit had its rows recomputed beside its sibling's: the same floats)
+            if (d.cache && mine && leaf_needs_net(games[wave].leaf_kind)) {
+                const GameLds &gs = games[wave];
+                Plane lme, lopp;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { lme.w[q] = gs.leaf[q]; lopp.w[q] = gs.leaf[4 + q]; }
+                float cx[TG::CPL];
+#pragma unroll
+                for (int i = 0; i < TG::CPL; i++) cx[i] = lane + 64 * i < TG::nn ? logits_l[wave * PG::RW + lane + 64 * i] : 0.0f;
+                cache_insert<N>(d, lme, lopp, gs.leaf_last, netid, lane, cx, vhid_l[wave * 64 + lane]);
+            }
         }
         // ---- tree step: wave g works on game g ----
         if (mine && (!(AZ_SEARCH_SKIP & 2) || idx == S))
@@ -394,6 +428,7 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
             d.leaf_kind[gb] = LEAF_NONE;
             unsigned long long *c = d.cnt + (size_t)gb * CNT_STRIDE;
             c[0] += cnt[0]; c[1] += cnt[1]; c[2] += cnt[2]; c[3] += cnt[3];
+            c[6] += cache_lookups; c[7] += cache_hits;
         }
     }
 }

@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 tag=$1; shift
 mkdir -p gpurun_out/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o $tag -- python3 bench.py --steps 2 --warmup 1 --no-episode --no-cpu "$@" > gpurun_out/prof/${tag}_run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o $tag -- python3 bench.py --steps 2 --warmup 1 --no-episode --no-cpu --no-emul "$@" > gpurun_out/prof/${tag}_run.log 2>&1
 python3 - <<PY
 import csv, json
 for r in list(csv.DictReader(open("gpurun_out/prof/${tag}_kernel_stats.csv")))[:7]:

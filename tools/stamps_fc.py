@@ -6,8 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import alphazero_piskvorky_amd as az
 from alphazero_piskvorky_amd import _capi
 from alphazero_piskvorky_amd.weights import synthetic_state_dict
-n, B = 15, 1024
-e = az.Engine(n, 5, 8, B)
+n, B = 15, 256
+e = az.Engine(n, 5, 8, B, engines=1)
 e.load_weights(synthetic_state_dict(n), 0)
 e.selfplay_begin(B, seed0=1)
 e.selfplay_step(1)
@@ -16,7 +16,7 @@ buf = np.zeros(tot, np.uint64)
 rc = _capi.lib().az_debug_stamps(e.h, buf.ctypes.data_as(C.c_void_p), -1)
 assert rc == 0
 fc = buf[B * 16:].reshape(-1, 8, 4).astype(np.int64)      # [wg][wave][stamp]
-nwg = 64 * 3
+nwg = (B // 16) * 3                                     # the throughput shape <2, 4>: three workgroups per row of 16 boards
 fc = fc[:nwg]
 live = fc[:, :, 2] > 0
 st = (fc[:, :, 1] - fc[:, :, 0])
