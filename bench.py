@@ -40,16 +40,34 @@ def net_flops(n, model="plain"):
     return trunk, fc
 
 
+def usable_cpus():
+    """CPUs this job may use: the affinity mask capped by the cgroup CPU quota (the GPU box grants a share of its hardware
+    threads; the library sizes its own host threads the same way, az_counters.host_cpus)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max" and float(period) > 0:
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = max(1, min(n, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(n, k, sims, sd, budget_games):
     """The CPU oracle (a C restatement of the reference algorithm, see oracle/az_oracle.c) on the host cores:
     one game per thread like self_play.py:29-45, first 2 plies of `budget_games` games."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as orc
-    try:
-        avail = len(os.sched_getaffinity(0))      # the CPUs this job may use (the box grants a share of its hardware threads)
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = min(avail, 64)
+    cores = min(usable_cpus(), 64)
     o = orc.Oracle(n, k, sims)
     net = orc.Net(n, sd)
     plies = 2
