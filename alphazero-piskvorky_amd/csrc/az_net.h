@@ -12,6 +12,7 @@
 // bit for bit), bias added afterwards.  conv k = (ky*3+kx)*Cin + ci; FC k ascending.
 #pragma once
 #include "az_tree.h"
+#include <type_traits>
 
 #ifdef AZ_STAMPS
 // diagnostic build only: per-workgroup phase time stamps (s_memtime) into a buffer no other code reads
@@ -164,13 +165,21 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
     constexpr int NTW = (AZ_NTW <= NT) ? AZ_NTW : NT;          // channel tiles per wave
     constexpr int NG = NT / NTW;                               // channel-tile groups
     constexpr int MG = (G::NW / NG) > 0 ? (G::NW / NG) : 1;    // cell-tile groups
-    constexpr int MTW = (MTL + MG - 1) / MG;
+    // cell tiles per wave: the first MTL % MG cell-tile groups take one more than the others.  The layer's body is
+    // instantiated for both counts and a wave runs the one that is its own (until round 3 every wave ran the larger count and
+    // threw the surplus tile away: 16 instead of 15 tile chains per SIMD in conv2 at n = 15).
+    constexpr int MT_FULL = MTL / MG, MT_REM = MTL % MG;
     constexpr int KST = CIN / 4;           // k-steps per tap
     constexpr int KS = 9 * KST;
     constexpr int KS4 = (KS + 3) / 4;
     const int ng = wave % NG, mg = wave / NG;       // wave is wave-uniform (readfirstlane) -> scalar control flow
     const int q = lane >> 4, r16 = lane & 15;
 
+    auto body = [&](auto mtw_c) __attribute__((always_inline)) {
+    constexpr int MTW = decltype(mtw_c)::value;
+    if constexpr (MTW == 0) {
+        if constexpr (OUT3) __syncthreads();       // a wave without a tile still meets the layer's barrier
+    } else {
     f32x4 acc[NTW][MTW];
 #pragma unroll
     for (int t = 0; t < NTW; t++)
@@ -308,6 +317,11 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
             }
         }
     }
+    }
+    };
+    if constexpr (MT_REM == 0) body(std::integral_constant<int, MT_FULL>{});
+    else if (mg < MT_REM) body(std::integral_constant<int, MT_FULL + 1>{});
+    else body(std::integral_constant<int, MT_FULL>{});
 }
 
 // policy_conv (128->4) and value_conv (128->2), 1x1 (net.py:64,69): D[head channel][cell] over the float32 conv3 image
