@@ -1724,11 +1724,6 @@ extern "C" int az_set_virtual_loss(az_engine *e, int leaves)
     if (e->run.open) return fail(e, AZ_ERR_STATE, "az_set_virtual_loss: an episode is open");
     if (leaves < 1 || leaves > VL_MAX) return fail(e, AZ_ERR_INVALID, "virtual-loss batching supports 1..%d leaves per batch", VL_MAX);
     if (leaves > 1 && e->reuse) return fail(e, AZ_ERR_INVALID, "subtree reuse and virtual-loss batching cannot be combined");
-    {
-        const char *fv = getenv("AZ_VL_FORCE");
-        if ((leaves > 1 || (fv && fv[0] == '1')) && e->leaf_symmetry)
-            return fail(e, AZ_ERR_INVALID, "virtual-loss batching and random-symmetry leaf evaluation cannot be combined");
-    }
     DEVICE_GUARD(e);
     if (leaves != e->vl) {
         for (Lane &L : e->lanes) {
@@ -1775,8 +1770,8 @@ extern "C" int az_set_leaf_symmetry(az_engine *e, int on)
 {
     if (!e) return AZ_ERR_INVALID;
     if (e->run.open) return fail(e, AZ_ERR_STATE, "az_set_leaf_symmetry: an episode is open");
-    if (on && (e->vl_kernel || e->reuse || e->cache.p))      // vl_kernel: also AZ_VL_FORCE=1 (the batched tree kernel with batches of one)
-        return fail(e, AZ_ERR_INVALID, "random-symmetry leaf evaluation cannot be combined with virtual-loss batching, subtree reuse or the evaluation cache");
+    if (on && (e->reuse || e->cache.p))
+        return fail(e, AZ_ERR_INVALID, "random-symmetry leaf evaluation cannot be combined with subtree reuse or the evaluation cache");
     if (on && e->cfg.eval_kind != AZ_EVAL_NET) return fail(e, AZ_ERR_INVALID, "random-symmetry leaf evaluation needs the net evaluator");
     e->leaf_symmetry = on ? 1 : 0;
     for (Lane &L : e->lanes) L.d.leaf_sym = on ? (int *)L.leaf_sym.p : nullptr;

@@ -619,8 +619,18 @@ __device__ __forceinline__ void vl_leaf_eval(const DevState &d, size_t it, const
     }
     float x[G::CPL];
     const float *lg = d.logits + it * G::RW;
+    if (d.leaf_sym) {
+        // the net saw this leaf under symmetry t: board cell j sits at image cell sym_src(t^-1, j)
+        const int ti = sym_inverse(d.leaf_sym[it]);
 #pragma unroll
-    for (int i = 0; i < G::CPL; i++) x[i] = lane + 64 * i < G::nn ? lg[lane + 64 * i] : 0.0f;
+        for (int i = 0; i < G::CPL; i++) {
+            const int j = lane + 64 * i, r = j / N;
+            x[i] = j < G::nn ? lg[sym_src(ti, r, j - r * N, N)] : 0.0f;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < G::CPL; i++) x[i] = lane + 64 * i < G::nn ? lg[lane + 64 * i] : 0.0f;
+    }
     const float h_l = d.vhid[it * 64 + lane];
     const float w2_l = d.v2w[netid][lane];
     const float b2 = d.v2b[netid][0];
@@ -822,6 +832,8 @@ __global__ __launch_bounds__(256) void k_step_vl(DevState d, int sims_done, int 
             d.leaf_last[it] = last;
             d.leaf_kind[it] = out_kind;
             d.depth[it] = depth;
+            // simulation sims_done + j of the search: its leaf is evaluation sims_done + j + 1 (0 = the root), as in k_step
+            if (d.leaf_sym) d.leaf_sym[it] = leaf_sym_of((int)(d.game_key0 + (unsigned)game), ply, sims_done + j + 1);
         }
         wave_mem_sync();
     }

@@ -286,7 +286,8 @@ int az_set_subtree_reuse(az_engine *e, int on);
  * ceil(num_simulations / L) dependent evaluation batches instead of num_simulations -- the lever for the latency-bound
  * uses (az_search, az_arena, episode tails).  Visit counts differ from the reference's sequential search, so parity is
  * against the oracle's restatement of this rule ("parity unpinned" by the reference); L = 1 is the reference's loop.
- * 1 <= leaves <= 32.  Not combinable with subtree reuse; not allowed while an episode is open. */
+ * 1 <= leaves <= 32.  Combines with random-symmetry leaf evaluation; not with subtree reuse.  Not allowed while an episode
+ * is open. */
 int az_set_virtual_loss(az_engine *e, int leaves);
 
 /* Opt-in: evaluation cache, the first item of the reference's TODO list (mcts.py:17 DEFAULT_CACHE_SIZE = 500_000,
@@ -308,8 +309,9 @@ int az_set_eval_cache(az_engine *e, int64_t entries);
  * named by its seed, which a rank playing the id block [lo, hi) of a larger episode passes as seed0 + lo -- so runs are
  * reproducible and independent of slots, lanes and ranks (az_search / az_search_callback: key 0).  Visit counts differ from the reference's (its net always sees the position
  * unrotated); parity is against the oracle's restatement of this rule (orc_cfg.leaf_sym, "parity unpinned" by the
- * reference).  Lock-step pipeline only; not combinable with virtual-loss batching, subtree reuse, the evaluation cache or
- * az_search_callback.  Not allowed while an episode is open. */
+ * reference).  Lock-step pipeline only; combines with virtual-loss batching (simulation s of a batch is evaluation s + 1 like
+ * in the sequential loop); not combinable with subtree reuse, the evaluation cache or az_search_callback.  Not allowed while
+ * an episode is open. */
 int az_set_leaf_symmetry(az_engine *e, int on);
 
 /* Opt-in: fp32-emulating conv trunks.  AZ_TRUNK_F32 (default) computes the net's forward (net.py:55-72) on the float32

@@ -511,7 +511,7 @@ void orc_net_eval_sym(const orc_net *N, int n, const float *planes, int t, float
 }
 int orc_leaf_sym_of(int game, int ply, int idx) { return orc_leaf_sym(game, ply, idx); }
 
-/* idx < 0: no symmetry (virtual-loss mode, which the option cannot be combined with) */
+/* idx: which evaluation of the search this is (0 = the root, s + 1 = simulation s, also within a virtual-loss batch); idx < 0: no symmetry */
 static void evaluate(const orc_cfg *cfg, const orc_net *net, const orc_state *s, float *P, float *v, int ply, int idx)
 {
     if (cfg->eval_kind == 1) { synth_eval(s, P, v); return; }
@@ -699,7 +699,7 @@ static int mcts_run(const orc_cfg *cfg, const orc_net *net, const orc_state *roo
                 for (int nd = node; nd >= 0; nd = t->nodes[nd].parent) t->nodes[nd].vl += 1;
             }
             for (int j = 0; j < nb; j++)
-                if (kind[j] == 0) evaluate(cfg, net, &sb[j], Pb[j], &vals[j], ply, -1);
+                if (kind[j] == 0) evaluate(cfg, net, &sb[j], Pb[j], &vals[j], ply, done + j + 1);   /* simulation done + j: evaluation done + j + 1 */
             for (int j = 0; j < nb; j++) {
                 const int node = leaf[j];
                 for (int nd = node; nd >= 0; nd = t->nodes[nd].parent) t->nodes[nd].vl -= 1;

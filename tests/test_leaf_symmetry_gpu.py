@@ -93,15 +93,41 @@ def test_leaf_symmetry_with_the_emulated_trunk_and_rejected_combinations():
     c = e.selfplay(4, seed0=3, max_plies=5)
     assert c["simulations"] == S * c["plies"] and int(e.records()["visits"].sum()) == S * c["plies"]
     e.set_trunk_mode("f32")
-    for call in (lambda: e.set_virtual_loss(4), lambda: e.set_subtree_reuse(True), lambda: e.set_eval_cache(1024)):
+    for call in (lambda: e.set_subtree_reuse(True), lambda: e.set_eval_cache(1024)):
         with pytest.raises(_capi.AzError):
             call()
-    e.set_leaf_symmetry(False)
-    e.set_virtual_loss(4)
-    with pytest.raises(_capi.AzError):
-        e.set_leaf_symmetry(True)
     e.close()
     s = az.Engine(5, 4, 8, 2, synthetic=True)
     with pytest.raises(_capi.AzError):
         s.set_leaf_symmetry(True)         # the synthetic evaluator is not a net
     s.close()
+
+
+@pytest.mark.parametrize("n,k,S,G,cut,L", [(5, 4, 40, 5, 0, 4), (9, 5, 30, 3, 6, 8), (15, 5, 24, 2, 4, 5)])
+def test_leaf_symmetry_with_virtual_loss_batching_bit_exact_vs_oracle(n, k, S, G, cut, L):
+    """The two opt-ins together (round 3; they were mutually exclusive): simulation s of a batch is evaluation s + 1 of the
+    search, exactly as in the sequential loop, so the symmetry hash needs no new definition.  Engine == oracle bit for bit
+    (oracle: orc_cfg.vl + orc_cfg.leaf_sym), in either order of switching the options on."""
+    seed0 = 8800
+    sd, onet = _nets(n, "plain")
+    o = orc.Oracle(n, k, S, leaf_sym=True, virtual_loss=L)
+    for order in (0, 1):
+        e = az.Engine(n, k, S, 3, log_table=orc.numpy_log_table(S))
+        e.load_weights(sd, 0)
+        if order == 0:
+            e.set_leaf_symmetry(True); e.set_virtual_loss(L)
+        else:
+            e.set_virtual_loss(L); e.set_leaf_symmetry(True)
+        c = e.selfplay(G, seed0=seed0, max_plies=cut)
+        rec = e.records(); nply, res = e.games()
+        e.close()
+        assert c["simulations"] == S * c["plies"]
+        off = 0
+        for g in range(G):
+            noise, us = orc.selfplay_tape(seed0 + g, n, maxply=cut or None)
+            r = o.selfplay_game(onet, noise, us, maxply=cut or None, game=seed0 + g)
+            Lg = int(nply[g]); sl = slice(off, off + Lg)
+            assert Lg == r["nply"], f"game {g}"
+            for key in ("actions", "boards", "visits", "pis"):
+                assert np.array_equal(rec[key][sl], r[key]), f"game {g}: {key} differs from the oracle (order {order})"
+            off += Lg
