@@ -558,7 +558,7 @@ static int alloc_items(az_engine *e, Lane &L, int leaves)
     ALLOC(logits, NI * (size_t)e->RW * 4); ALLOC(vhid, NI * 64 * 4);
     ALLOC(pol_feat, NI * (size_t)((((e->cfg.model == AZ_MODEL_RESNET ? 3 : 6) * e->nn + 3) / 4) * 4) * 4);   // feature rows [NI][FROW], zero tail stays zero
 #ifdef AZ_STAMPS
-    ALLOC(dbg, (NI * 16 + 4096 * 32) * sizeof(unsigned long long));
+    ALLOC(dbg, (NI * 16 + 4096 * 32 + NI * 32) * sizeof(unsigned long long));     // trunk stamps | k_fc stamps | conv3 per-wave stamps
 #endif
     if (e->split_max > 0)    // zeroed once: the padding ring of the packed images is never written afterwards
         ALLOC(scratch, (size_t)e->ops->split_scratch_floats((int)NI, e->cfg.model) * sizeof(float));

@@ -32,6 +32,10 @@
 #ifndef AZ_SEQ
 #define AZ_SEQ 1         // board groups per trunk workgroup (0 = persistent grid stride); all variants measure the same
 #endif
+#ifndef AZ_PRIO_ALT
+#define AZ_PRIO_ALT 2    // the waves sharing a SIMD take turns with the issue priority in the conv main loops: 2 = per tap (default), 1 = per
+                         // 16-channel group (the same speed, two VGPRs over the budget at n = 15), 0 = off
+#endif
 #ifndef AZ_NTW
 #define AZ_NTW 1         // channel tiles per wave in the conv layers (1: 15 cell tiles per wave, no surplus tile)
 #endif
@@ -157,8 +161,15 @@ template <class G, int CIN, int COUT, int MODE, int NTL = COUT / 16, int MTL = G
 __device__ __forceinline__ void conv_layer(const float *in, float *out, const float *__restrict__ wp,
                                            const float *__restrict__ bias, const unsigned short *wpos,
                                            const unsigned short *cellof, int wave, int lane, int nt_base = 0,
-                                           int mt_base = 0, int mt_cnt = MTL, int out_pos_off = 0, const float *res = nullptr)
+                                           int mt_base = 0, int mt_cnt = MTL, int out_pos_off = 0, const float *res = nullptr,
+                                           unsigned long long *lst = nullptr)
 {
+    // diagnostic builds only (-DAZ_STAMPS): per-wave time stamps of a layer's phases into lst[wave * 4 + k]
+#ifdef AZ_STAMPS
+#define AZ_LSTAMP(k) do { if (lst && lane == 0) lst[wave * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AZ_LSTAMP(k) do { } while (0)
+#endif
     constexpr bool OUT3 = MODE == CONV_OUT3 || MODE == CONV_OUT3_RESIDUAL;
     constexpr bool SUBSET = MTL < G::MT;                       // a tile-split kernel: waves without a tile skip the layer
     constexpr int NT = NTL;                                    // channel tiles handled by this workgroup
@@ -180,6 +191,7 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
     if constexpr (MTW == 0) {
         if constexpr (OUT3) __syncthreads();       // a wave without a tile still meets the layer's barrier
     } else {
+    AZ_LSTAMP(0);
     f32x4 acc[NTW][MTW];
 #pragma unroll
     for (int t = 0; t < NTW; t++)
@@ -238,6 +250,9 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
         }
         float4 a0[MTW], a1[MTW];
         float4 bw[NTW][NQ], bnx[NTW][NQ];
+#if AZ_PRIO_ALT
+        const int prio_turn = (wave >> 2) % (G::NW / 4);        // scalar: which of the waves sharing a SIMD this one is
+#endif
 #pragma unroll
         for (int t = 0; t < NTW; t++)
 #pragma unroll
@@ -254,6 +269,17 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
             const int dnext = ((tn / 3) * G::PW + (tn % 3)) - ((tap / 3) * G::PW + (tap % 3)) - (NQ - 1) * 4 * G::CS;
 #pragma unroll
             for (int sq = 0; sq < NQ; sq++) {
+#if AZ_PRIO_ALT
+                // The waves that share a SIMD (w, w + 4, ...) run the same program; left alone, one of them wins the issue
+                // arbitration every time, finishes the layer early and leaves its partner to run the rest alone -- and ONE
+                // wave issues an MFMA only every ~44 cycles (measured: conv3 at n = 15, waves 4-7 done after 102.6 k cycles,
+                // waves 0-3 after 151.6 k; the matrix pipe needs 138.2 k).  Taking turns with the priority keeps them
+                // level, so that the pipe has two streams to draw from until the end.
+                if (AZ_PRIO_ALT == 1 || sq == 0) {      // 1: turns change every 16-channel group, 2: every tap
+                    if (((AZ_PRIO_ALT == 1 ? tap * NQ + sq : tap) % (G::NW / 4)) == prio_turn) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+#endif
                 float4 *cur = (sq & 1) ? a1 : a0;
                 float4 *nxt = (sq & 1) ? a0 : a1;
                 const int dstep = sq + 1 < NQ ? 4 * G::CS : dnext;
@@ -281,9 +307,14 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
 #pragma unroll
                 for (int j = 0; j < NQ; j++) bw[t][j] = bnx[t][j];
         }
+#if AZ_PRIO_ALT
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
     }
+    AZ_LSTAMP(1);
     if constexpr (OUT3) __syncthreads();   // every wave has finished reading the conv3 input image
+    AZ_LSTAMP(2);
 #pragma unroll
     for (int t = 0; t < NTW; t++) {
         const int nt = nt_base + ng * NTW + t;
@@ -317,6 +348,7 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
             }
         }
     }
+    AZ_LSTAMP(3);
     }
     };
     if constexpr (MT_REM == 0) body(std::integral_constant<int, MT_FULL>{});
@@ -464,7 +496,12 @@ __device__ __forceinline__ void trunk_group(const DevState &d, const NetWeights 
     conv_layer<G, 32, 64, CONV_OUT_PACKED>(inA, inB, w.c2, w.c2b, wpos, cellof, wave, lane);
     __syncthreads();
     AZ_STAMP(3);
-    conv_layer<G, 64, 128, CONV_OUT3>(inB, lds, w.c3, w.c3b, wpos, cellof, wave, lane);
+#ifdef AZ_STAMPS
+    unsigned long long *lst3 = dbg ? dbg + (size_t)d.B * 16 + 4096 * 32 + (size_t)grp * 32 : nullptr;      // behind k_fc's stamps
+#else
+    unsigned long long *lst3 = nullptr;
+#endif
+    conv_layer<G, 64, 128, CONV_OUT3>(inB, lds, w.c3, w.c3b, wpos, cellof, wave, lane, 0, 0, G::MT, 0, nullptr, lst3);
     __syncthreads();
     AZ_STAMP(4);
     trunk_heads<G>(d, w, net_id, feat, lds, cellof, b0, wave, lane);

@@ -39,6 +39,16 @@ if ng:
     ghz = (t[:, 5] - t[:, 0]) / (rt[:, 1] - rt[:, 0]) * 0.1
     print(f"in-kernel clock (d s_memtime / d s_memrealtime x 100 MHz): median {np.median(ghz):.3f} GHz, min {ghz.min():.3f}, max {ghz.max():.3f}; "
           f"workgroup duration median {np.median(rt[:, 1] - rt[:, 0]) * 10:.0f} ns")
+# conv3 per wave: entry, all MFMAs issued, past the barrier, epilogue written (slots behind k_fc's stamps)
+allb = np.zeros(B * 16 + 4096 * 32 + B * 32, np.uint64)
+if _capi.lib().az_debug_stamps(e.h, allb.ctypes.data_as(C.c_void_p), -1) == 0:
+    c3 = allb[B * 16 + 4096 * 32:].reshape(B, 8, 4).astype(np.int64)[ok]
+    if len(c3) and (np.diff(c3, axis=2) >= 0).all():
+        dd = np.diff(c3, axis=2)
+        print("conv3 per wave: main loop (entry -> last MFMA issued) mean %.0f  [min %d max %d];  wait at the barrier mean %.0f [max %d];  epilogue mean %.0f" %
+              (dd[:, :, 0].mean(), dd[:, :, 0].min(), dd[:, :, 0].max(), dd[:, :, 1].mean(), dd[:, :, 1].max(), dd[:, :, 2].mean()))
+        print("conv3: first wave in -> last wave out of the epilogue, mean %.0f" % (c3[:, :, 3].max(axis=1) - c3[:, :, 0].min(axis=1)).mean())
+        print("conv3 main loop per wave (mean over workgroups):", np.round(dd[:, :, 0].mean(axis=0)).astype(int).tolist())
 tot = t[:, 5] - t[:, 0]
 print("total per WG mean", tot.mean(), " kernel span", t[:, 5].max() - t[:, 0].min())
 starts = np.sort(t[:, 0] - t[:, 0].min())
