@@ -18,12 +18,16 @@ void trunk(const LaunchCtx &c, int net_id)
     if (c.model == 1) {
         typedef ResGeo<N> G;
         dim3 gt((c.dv.B + G::G - 1) / G::G), bt(G::NW * 64);
+#ifndef AZ_EXPERIMENT     // experiment builds (another wave count for the float32 trunk) leave the emulated trunks out
         if (c.emul == EMUL_BF16X3) hipLaunchKernelGGL((k_trunk_res_emul<N, EMUL_BF16X3>), gt, dim3(ResGeoEmul<N>::NW * 64), 0, c.stream, c.dv, c.rw[net_id], net_id, c.feat);
         else if (c.emul == EMUL_F16X2) hipLaunchKernelGGL((k_trunk_res_emul<N, EMUL_F16X2>), gt, dim3(ResGeoEmul<N>::NW * 64), 0, c.stream, c.dv, c.rw[net_id], net_id, c.feat);
-        else hipLaunchKernelGGL(k_trunk_res<N>, gt, bt, 0, c.stream, c.dv, c.rw[net_id], net_id, c.feat);
+        else
+#endif
+        hipLaunchKernelGGL(k_trunk_res<N>, gt, bt, 0, c.stream, c.dv, c.rw[net_id], net_id, c.feat);
     } else {
         typedef NetGeo<N> G;
         const int ngroups = (c.dv.B + G::G - 1) / G::G;
+#ifndef AZ_EXPERIMENT
         if (c.emul == EMUL_BF16X3) {
             hipLaunchKernelGGL((k_trunk_emul<N, EMUL_BF16X3>), dim3(ngroups), dim3(G::NW * 64), 0, c.stream, c.dv, c.w[net_id], net_id, c.feat, c.dbg);
             return;
@@ -32,6 +36,7 @@ void trunk(const LaunchCtx &c, int net_id)
             hipLaunchKernelGGL((k_trunk_emul<N, EMUL_F16X2>), dim3(ngroups), dim3(G::NW * 64), 0, c.stream, c.dv, c.w[net_id], net_id, c.feat, c.dbg);
             return;
         }
+#endif
         dim3 gt(AZ_SEQ == 0 ? (ngroups < 256 ? ngroups : 256) : (ngroups + AZ_SEQ - 1) / AZ_SEQ), bt(G::NW * 64);
         hipLaunchKernelGGL(k_trunk<N>, gt, bt, 0, c.stream, c.dv, c.w[net_id], net_id, c.feat, c.dbg);
     }

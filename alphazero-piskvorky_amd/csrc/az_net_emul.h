@@ -235,6 +235,10 @@ enum { EMUL_OUT_IMAGE = 0, EMUL_OUT_HEADS = 1,      // where the result goes
 // (k = 4 (lane >> 4) + register), so each wave multiplies its channel tile with its 16 columns of the head weights
 // (hw: [tile][part][lane][4 x 16 bit], rows = the NH head channels) and leaves partial sums [channel tile][head][cell] at out
 // after the barrier; the caller adds the channel tiles up.
+// the priority turns of the main loop apply unless the geometry opts out (ResGeoEmul::EMUL_PRIO_TURNS = false)
+template <class G, class = void> struct emul_prio_turns : std::true_type {};
+template <class G> struct emul_prio_turns<G, std::enable_if_t<!G::EMUL_PRIO_TURNS>> : std::false_type {};
+
 template <class G, int CIN, int COUT, int MODE, int NH, int SCH>
 __device__ __forceinline__ void conv_layer_emul(const uint4 *in, void *out, const uint4 *__restrict__ wp,
                                                 const uint4 (&w0)[Emul<SCH>::NS], const float (&bco)[4],
@@ -275,6 +279,15 @@ __device__ __forceinline__ void conv_layer_emul(const uint4 *in, void *out, cons
 #pragma unroll
         for (int sq = 0; sq < KBT; sq++) {
             const int kb = tap * KBT + sq;
+#if AZ_PRIO_ALT
+            // the waves sharing a SIMD take turns with the issue priority, K-block by K-block (az_net.h conv_layer: left alone,
+            // one of them wins every arbitration and leaves its partner to finish the layer alone); measured: f16x2 8.24 -> 8.52 M
+            // expansions/s, bf16x3 unchanged
+            if constexpr (emul_prio_turns<G>::value) {
+                if ((kb % (G::NW / 4)) == ((wave >> 2) % (G::NW / 4))) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+#endif
             emul_weights<KB, NS>(wp, ng, kb + 1 < KB ? kb + 1 : kb, lane, wn);
             __builtin_amdgcn_sched_barrier(0);         // the next K-block's weights are requested before this block's MFMAs, not after
             const int off = sq * 4 * NS * G::CS + toff;    // a K-block = 4 channel groups x NS part planes
@@ -297,6 +310,9 @@ __device__ __forceinline__ void conv_layer_emul(const uint4 *in, void *out, cons
             for (int s = 0; s < NS; s++) wc[s] = wn[s];
         }
     }
+#if AZ_PRIO_ALT
+    if constexpr (emul_prio_turns<G>::value) __builtin_amdgcn_s_setprio(0);
+#endif
     // relu(acc + bias [+ skip]) of the wave's tiles
     float v[MTW][4];
 #pragma unroll
@@ -358,8 +374,10 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk_emul(DevState d, NetWeight
     constexpr int NTH = AZ_NW * 64, NS = E::NS;
     constexpr int XF = 32 * NS * G::CS;          // floats of the 64-channel image: 8 channel groups x NS planes of CS 16-byte slots
     static_assert(XF <= G::LDSF, "the split image does not fit the trunk's LDS");
+#ifndef AZ_EXPERIMENT     // experiment builds of the float32 trunk with another wave count never run this kernel
     static_assert(AZ_NW == 8, "the emulated trunk is laid out for 8 waves: 2 / 4 / 8 channel tiles in conv1 / conv2 / conv3");
     static_assert(AZ_NW * 6 * G::MR <= G::LDSF, "head-conv partial sums do not fit the trunk's LDS");
+#endif
     __shared__ __attribute__((aligned(16))) float lds[G::LDSF];
     __shared__ unsigned short wpos[G::MR];
     __shared__ unsigned short cellof[G::MR];
@@ -493,6 +511,7 @@ __global__ __launch_bounds__(AZ_NW * 64) void k_trunk_emul(DevState d, NetWeight
 template <int N>
 struct ResGeoEmul : ResGeo<N> {
     static constexpr int NW = AZ_RES_EMUL_NW ? AZ_RES_EMUL_NW : ResGeo<N>::NW;
+    static constexpr bool EMUL_PRIO_TURNS = false;    // measured: the turns cost this kernel 4 % (f16x2 is at the register limit: they spill)
 };
 
 template <int N, int SCH>
