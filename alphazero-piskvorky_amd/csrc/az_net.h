@@ -36,6 +36,9 @@
 #define AZ_PRIO_ALT 2    // the waves sharing a SIMD take turns with the issue priority in the conv main loops: 2 = per tap (default), 1 = per
                          // 16-channel group (the same speed, two VGPRs over the budget at n = 15), 0 = off
 #endif
+#ifndef AZ_UNROLL_TAPS
+#define AZ_UNROLL_TAPS 1     // the conv main loops with all nine taps unrolled (constant fragment offsets, no per-tap address arithmetic)
+#endif
 #ifndef AZ_NTW
 #define AZ_NTW 1         // channel tiles per wave in the conv layers (1: 15 cell tiles per wave, no surplus tile)
 #endif
@@ -259,14 +262,21 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
             for (int j = 0; j < NQ; j++) bw[t][j] = wp4[t][(size_t)j * 64];
 #pragma unroll
         for (int i = 0; i < MTW; i++) a0[i] = in4[ra[i]];
+        // AZ_UNROLL_TAPS: the nine taps unrolled, so that every fragment address is the tile's base register + a constant (the
+        // ds_read's 16-bit immediate: at most ((NQ - 1) 4 CS + 2 PW + 2) x 16 B = 58.9 KB at n = 15) and the weight registers
+        // of consecutive taps are renamed instead of copied.  The rolled loop kept a running index per tile and recomputed
+        // the bases every tap: 0.82 vector instructions per MFMA in conv3 -- and the float32 MFMA leaves the SIMD's vector
+        // issue so little room that those showed one for one: 35.2 cycles per MFMA instead of 32 (measured with the LDS
+        // reads AND the weight fetches taken out: still 35).
+#if AZ_UNROLL_TAPS
+#pragma unroll
+#endif
         for (int tap = 0; tap < 9; tap++) {
             const int tn = tap + 1 < 9 ? tap + 1 : tap;
 #pragma unroll
             for (int t = 0; t < NTW; t++)
 #pragma unroll
                 for (int j = 0; j < NQ; j++) bnx[t][j] = wp4[t][(size_t)(tn * NQ + j) * 64];
-            // float4-index step from the last group of this tap to the first group of the next tap
-            const int dnext = ((tn / 3) * G::PW + (tn % 3)) - ((tap / 3) * G::PW + (tap % 3)) - (NQ - 1) * 4 * G::CS;
 #pragma unroll
             for (int sq = 0; sq < NQ; sq++) {
 #if AZ_PRIO_ALT
@@ -282,9 +292,12 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
 #endif
                 float4 *cur = (sq & 1) ? a1 : a0;
                 float4 *nxt = (sq & 1) ? a0 : a1;
-                const int dstep = sq + 1 < NQ ? 4 * G::CS : dnext;
+                // float4 offset of the NEXT group's fragments from the tile's base: next 16-channel group of this tap, or the
+                // first group of the next tap (the last group of all reads its own again: never used)
+                const int gtap = sq + 1 < NQ ? tap : tn, gsq = sq + 1 < NQ ? sq + 1 : (tap + 1 < 9 ? 0 : sq);
+                const int noff = gsq * 4 * G::CS + (gtap / 3) * G::PW + (gtap % 3);
 #pragma unroll
-                for (int i = 0; i < MTW; i++) { ra[i] += dstep; nxt[i] = in4[ra[i]]; }
+                for (int i = 0; i < MTW; i++) nxt[i] = in4[ra[i] + noff];
 #pragma unroll
                 for (int e = 0; e < 4; e++)
 #pragma unroll
