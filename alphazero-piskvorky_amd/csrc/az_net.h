@@ -145,7 +145,9 @@ __device__ __forceinline__ int pk_index(int ci, int pos)
     return ((((ci >> 4) * 4 + (ci & 3)) * GEO::CS + pos) << 2) + ((ci >> 2) & 3);
 }
 enum { CONV_OUT_PACKED = 0, CONV_OUT3 = 1, CONV_OUT_RESIDUAL = 2,    // RESIDUAL: relu(acc + bias + out[same index]) in place
-       CONV_OUT3_RESIDUAL = 3 };   // relu(acc + bias + res[packed index]) into the [co][cell] tile (the last block of a tile-split ResidualBlock trunk)
+       CONV_OUT3_RESIDUAL = 3,     // relu(acc + bias + res[packed index]) into the [co][cell] tile (the last block of a tile-split ResidualBlock trunk)
+       CONV_OUT3_PK = 4 };         // conv3 of the fused trunk: the output packed by tile cell, float index ((cg*4 + q)*MR + m)*4 + e for channel
+                                   // 16 cg + 4 e + q -- no padding ring (a 1x1 conv reads it), so that the heads' B operands of four k-steps are ONE ds_read_b128
 
 // One conv layer on the workgroup's LDS image, computed as D[co][cell] = sum_k W[co][k] * X[k][cell]:
 // the weight fragment is the MFMA A operand (row = output channel), the activation fragment the B operand
@@ -173,7 +175,7 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
 #else
 #define AZ_LSTAMP(k) do { } while (0)
 #endif
-    constexpr bool OUT3 = MODE == CONV_OUT3 || MODE == CONV_OUT3_RESIDUAL;
+    constexpr bool OUT3 = MODE == CONV_OUT3 || MODE == CONV_OUT3_RESIDUAL || MODE == CONV_OUT3_PK;
     constexpr bool SUBSET = MTL < G::MT;                       // a tile-split kernel: waves without a tile skip the layer
     constexpr int NT = NTL;                                    // channel tiles handled by this workgroup
     constexpr int NTW = (AZ_NTW <= NT) ? AZ_NTW : NT;          // channel tiles per wave
@@ -346,7 +348,10 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
                     const int co = nt * 16 + q * 4 + rg;      // = 16*cg + 4*e + q' with cg = nt, e = q, q' = rg
                     float v = acc[t][i][rg] + bco[rg];
                     v = v > 0.0f ? v : 0.0f;
-                    if constexpr (MODE == CONV_OUT3_RESIDUAL) {
+                    if constexpr (MODE == CONV_OUT3_PK) {
+                        // co = 16 nt + 4 q + rg  ->  plane (nt, rg), component q: the 64 lanes of a store cover 256 contiguous bytes
+                        out[(((nt * 4 + rg) * G::MR + m) << 2) + q] = v;
+                    } else if constexpr (MODE == CONV_OUT3_RESIDUAL) {
                         float r = acc[t][i][rg] + bco[rg] + (valid ? res[pk_index<GO>(co, pos)] : 0.0f);
                         out[co * O3S + mt * 16 + r16 + (SUBSET ? 0 : mt_base * 16)] = r > 0.0f ? r : 0.0f;
                     } else if constexpr (OUT3) out[co * O3S + mt * 16 + r16 + (SUBSET ? 0 : mt_base * 16)] = v;
@@ -382,21 +387,26 @@ __device__ __forceinline__ void trunk_heads(const DevState &d, const NetWeights 
     for (int rg = 0; rg < 4; rg++) hb[rg] = (q * 4 + rg) < 6 ? w.hdb[q * 4 + rg] : 0.0f;
     constexpr int HT = (G::MT + AZ_NW - 1) / AZ_NW;     // tiles per wave
     f32x4 acc[HT];
-    const float *ip[HT];
+    // the conv3 image is packed by tile cell (CONV_OUT3_PK): lane (q, r16) reads the float4 of plane (s4, q) at its cell -- the B
+    // operands of k-steps 4 s4 .. 4 s4 + 3 (channels 16 s4 + 4 e + q)
+    const float4 *ip[HT];
 #pragma unroll
     for (int i = 0; i < HT; i++) {
         const int mt = wave + AZ_NW * i;
         acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        ip[i] = lds + q * G::CS3 + (mt < G::MT ? mt : 0) * 16 + r16;
+        ip[i] = reinterpret_cast<const float4 *>(lds) + q * G::MR + (mt < G::MT ? mt : 0) * 16 + r16;
     }
 #pragma unroll
     for (int s4 = 0; s4 < 8; s4++) {
         const float4 bq = wp4[s4 * 64];
         const float be[4] = {bq.x, bq.y, bq.z, bq.w};
+        float4 av[HT];
+#pragma unroll
+        for (int i = 0; i < HT; i++) av[i] = ip[i][s4 * 4 * G::MR];
 #pragma unroll
         for (int e = 0; e < 4; e++)
 #pragma unroll
-            for (int i = 0; i < HT; i++) acc[i] = mfma4(be[e], ip[i][(s4 * 16 + 4 * e) * G::CS3], acc[i]);
+            for (int i = 0; i < HT; i++) acc[i] = mfma4(be[e], e == 0 ? av[i].x : e == 1 ? av[i].y : e == 2 ? av[i].z : av[i].w, acc[i]);
     }
 #pragma unroll
     for (int i = 0; i < HT; i++) {
@@ -514,7 +524,7 @@ __device__ __forceinline__ void trunk_group(const DevState &d, const NetWeights 
 #else
     unsigned long long *lst3 = nullptr;
 #endif
-    conv_layer<G, 64, 128, CONV_OUT3>(inB, lds, w.c3, w.c3b, wpos, cellof, wave, lane, 0, 0, G::MT, 0, nullptr, lst3);
+    conv_layer<G, 64, 128, CONV_OUT3_PK>(inB, lds, w.c3, w.c3b, wpos, cellof, wave, lane, 0, 0, G::MT, 0, nullptr, lst3);
     __syncthreads();
     AZ_STAMP(4);
     trunk_heads<G>(d, w, net_id, feat, lds, cellof, b0, wave, lane);
