@@ -272,7 +272,7 @@ __device__ __forceinline__ void conv_layer_emul(const uint4 *in, void *out, cons
     uint4 fa[2][NS];
 #pragma unroll
     for (int s = 0; s < NS; s++) fa[0][s] = in[ra[0] + s * G::CS];
-    for (int tap = 0; tap < 9; tap++) {
+    for (int tap = 0; tap < 9; tap++) {      // rolled: unrolling the taps here measured nothing (the K-block loop inside is already clean)
         const int toff = (tap / 3) * G::PW + (tap % 3);
         const int tn = tap + 1 < 9 ? tap + 1 : tap;
         const int toffn = (tn / 3) * G::PW + (tn % 3);
