@@ -119,7 +119,7 @@ void fc(const LaunchCtx &c, int net_id)
 
 void step(const LaunchCtx &c, int rootN, int do_select)
 {
-    dim3 g((c.d.B + 3) / 4), b(256);
+    dim3 g((c.d.B + AZ_STEP_WAVES - 1) / AZ_STEP_WAVES), b(AZ_STEP_WAVES * 64);
     const size_t lds = (size_t)(c.d.S + 2) * sizeof(double);   // sqrt table
     if (c.synthetic)
         hipLaunchKernelGGL((k_step<N, true>), g, b, lds, c.stream, c.d, rootN, do_select);

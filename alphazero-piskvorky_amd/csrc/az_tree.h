@@ -287,21 +287,24 @@ __global__ void k_begin(DevState d)
 #endif  // AZ_ENGINE_TU
 
 // ------------------------------------------------------------------------------------------------
+#ifndef AZ_STEP_WAVES
+#define AZ_STEP_WAVES 4      // games (wavefronts) per k_step workgroup
+#endif
 // k_step: consume the evaluation of the pending leaf (expand + backup), then select the next leaf.
 // Latency-bound (one wave per game, ~4 waves per CU): every load that does not depend on another load is
 // issued up front in one round trip; the sqrt table lives in LDS; the chosen edge is broadcast by shuffle.
 // Dynamic LDS: (S + 2) doubles.
 // ------------------------------------------------------------------------------------------------
 template <int N, bool SYNTH>
-__global__ __launch_bounds__(256) void k_step(DevState d, int rootN, int do_select)
+__global__ __launch_bounds__(AZ_STEP_WAVES * 64) void k_step(DevState d, int rootN, int do_select)
 {
     typedef TreeGeo<N> G;
     extern __shared__ double sq_lds[];                 // np.sqrt(N + 1e-8), N = 0..S+1 (mcts.py:73)
     const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.x * AZ_STEP_WAVES + (threadIdx.x >> 6);
     const bool inb = b < d.B;
     const int bb = inb ? b : 0;
-    for (int i = threadIdx.x; i < d.S + 2; i += 256) sq_lds[i] = d.sqrt_table[i];
+    for (int i = threadIdx.x; i < d.S + 2; i += AZ_STEP_WAVES * 64) sq_lds[i] = d.sqrt_table[i];
 
     // ---- independent loads, all in flight together ----
     const int status = d.s_status[bb];
