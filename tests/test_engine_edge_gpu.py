@@ -424,3 +424,42 @@ def test_auto_lanes_and_lane_limits():
     e.close()
     with pytest.raises(az.AzError):
         az.Engine(9, 5, 8, 64, engines=17, synthetic=True)
+
+
+@pytest.mark.parametrize("n,k,S,cut,model", [(15, 5, 24, 5, "plain"), (9, 5, 30, 6, "plain"), (15, 5, 16, 3, "resnet")])
+def test_every_kernel_shape_gives_the_same_episode(n, k, S, cut, model):
+    """The library picks kernel shapes by occupancy (round 3): the fused trunk or the tile-split one (at most 64 active slots of
+    a lane), `k_fc<1, 1>` (at most 4 rows of 16 boards) or `k_fc<2, 4>`.  The same 96 games on 96 slots in one lane (fused trunk,
+    throughput FC), on 96 slots in three lanes (32 each: tile-split trunk, latency FC) and on 8 slots (everything small, eleven
+    refills) must give identical records, and the first games must be the oracle's, bit for bit."""
+    if model == "resnet":
+        from alphazero_piskvorky_amd.net import fold_resnet_state_dict
+        from alphazero_piskvorky_amd.weights import synthetic_resnet_state_dict
+        sd = synthetic_resnet_state_dict(n)
+        onet = orc.Net(n, resnet_tensors=fold_resnet_state_dict(sd))
+    else:
+        sd = weights_from_fixture(n, "seeded")
+        onet = orc.Net(n, sd)
+    G, seed0 = 96, 5150
+    out = []
+    for slots, lanes in ((96, 1), (96, 3), (8, 1)):
+        e = az.Engine(n, k, S, slots, engines=lanes, log_table=orc.numpy_log_table(S), model=model)
+        e.load_weights(sd, 0)
+        e.selfplay(G, seed0=seed0, max_plies=cut)
+        out.append((e.records(), e.games()))
+        e.close()
+    for rec, games in out[1:]:
+        for key in out[0][0]:
+            assert np.array_equal(rec[key], out[0][0][key]), key
+        assert np.array_equal(games[0], out[0][1][0]) and np.array_equal(games[1], out[0][1][1])
+    rec, (nply, _) = out[0]
+    o = orc.Oracle(n, k, S)
+    off = 0
+    for g in range(3):
+        noise, us = orc.selfplay_tape(seed0 + g, n, maxply=cut)
+        r = o.selfplay_game(onet, noise, us, maxply=cut)
+        L = int(nply[g])
+        assert L == r["nply"]
+        for key in ("actions", "visits", "pis"):
+            assert np.array_equal(rec[key][off:off + L], r[key]), f"game {g}: {key}"
+        off += L
