@@ -84,11 +84,37 @@ __device__ __forceinline__ float wave_sum_butterfly(float v)
     for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m, 64);
     return v;
 }
+// Cross-lane moves on the DPP path (no LDS round trip, unlike __shfl's ds_bpermute).  Only patterns whose meaning leaves no
+// room for a direction convention: the two quad permutes that are xor 1 / xor 2, and the two mirrors.  After the four steps
+// below every lane of a 16-lane row holds the row's result of an idempotent, commutative reduction (max, min); the four rows
+// are combined through v_readlane.  max and min do not depend on the order of their operands, so these give the same bits
+// as the butterfly they replace (measured on the tree step of the 5x5 search kernel: one selection level 3.0 k -> see DESIGN).
+#define AZ_DPP_XOR1 0xB1         // quad_perm [1, 0, 3, 2]
+#define AZ_DPP_XOR2 0x4E         // quad_perm [2, 3, 0, 1]
+#define AZ_DPP_HALF_MIRROR 0x141 // lane i <- lane 7 - i within every 8 lanes
+#define AZ_DPP_MIRROR 0x140      // lane i <- lane 15 - i within every 16 lanes
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v)
+{
+    return __hiloint2double(dpp_i<CTRL>(__double2hiint(v)), dpp_i<CTRL>(__double2loint(v)));
+}
+__device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double lane_d(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
 __device__ __forceinline__ float wave_max_f(float v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
-    return v;
+    v = fmaxf(v, dpp_f<AZ_DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f<AZ_DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f<AZ_DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f<AZ_DPP_MIRROR>(v));
+    return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
 }
 __device__ __forceinline__ double wave_max_d(double v)
 {
@@ -111,17 +137,39 @@ __device__ __forceinline__ unsigned wave_xor_u(unsigned v)
     for (int m = 32; m >= 1; m >>= 1) v = v ^ (unsigned)__shfl_xor((int)v, m, 64);
     return v;
 }
-// argmax with first-index tie-break: max score, then min index (mcts.py:71 "first maximal child")
+__device__ __forceinline__ double max_d(double a, double b) { return b > a ? b : a; }
+__device__ __forceinline__ int min_i(int a, int b) { return b < a ? b : a; }
+// argmax with first-index tie-break: max score, then min index (mcts.py:71 "first maximal child"); idx < 0 = no candidate in
+// this lane.  Two order-independent reductions: the maximum of the candidates' scores, then the minimum index among the
+// lanes that hold it.
 __device__ __forceinline__ void wave_argmax(double &s, int &idx)
 {
+    double m = idx >= 0 ? s : -INFINITY;
+    m = max_d(m, dpp_d<AZ_DPP_XOR1>(m));
+    m = max_d(m, dpp_d<AZ_DPP_XOR2>(m));
+    m = max_d(m, dpp_d<AZ_DPP_HALF_MIRROR>(m));
+    m = max_d(m, dpp_d<AZ_DPP_MIRROR>(m));
+    m = max_d(max_d(lane_d(m, 0), lane_d(m, 16)), max_d(lane_d(m, 32), lane_d(m, 48)));
+    int c = (idx >= 0 && s == m) ? idx : 0x7FFFFFFF;
+    c = min_i(c, dpp_i<AZ_DPP_XOR1>(c));
+    c = min_i(c, dpp_i<AZ_DPP_XOR2>(c));
+    c = min_i(c, dpp_i<AZ_DPP_HALF_MIRROR>(c));
+    c = min_i(c, dpp_i<AZ_DPP_MIRROR>(c));
+    c = min_i(min_i(__builtin_amdgcn_readlane(c, 0), __builtin_amdgcn_readlane(c, 16)),
+              min_i(__builtin_amdgcn_readlane(c, 32), __builtin_amdgcn_readlane(c, 48)));
+    idx = c == 0x7FFFFFFF ? -1 : c;
+    s = m;
+}
+
+// value_fc2 (net.py:70): acc = fma(h[i], w2[i], acc) for i = 0 .. 63 in this order, the operands held one per lane.  Every lane
+// computes the same chain; the operands come through v_readlane (until round 3: two ds_bpermutes and an LDS round trip per
+// step, 5.9 k of the 14 k cycles of a tree step).
+__device__ __forceinline__ float value_fc2_chain(float h_l, float w2_l)
+{
+    float acc = 0.0f;
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        double os = __shfl_xor(s, m, 64);
-        int oi = __shfl_xor(idx, m, 64);
-        bool take = (oi >= 0) && (idx < 0 || os > s || (os == s && oi < idx));
-        s = take ? os : s;
-        idx = take ? oi : idx;
-    }
+    for (int i = 0; i < 64; i++) acc = __builtin_fmaf(lane_f(h_l, i), lane_f(w2_l, i), acc);
+    return acc;
 }
 
 // ---------------------------------------------------------------------------------------

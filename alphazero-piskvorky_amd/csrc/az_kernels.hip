@@ -179,9 +179,9 @@ void search_t(const LaunchCtx &c)
         dim3 g((c.d.B + GP - 1) / GP), b(AZ_NW * 64);
         const size_t dyn = (size_t)GP * c.d.R * N * N * sizeof(Edge);
         if (c.synthetic)
-            hipLaunchKernelGGL((k_search<N, GP, true>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1]);
+            hipLaunchKernelGGL((k_search<N, GP, true>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1], c.dbg);
         else
-            hipLaunchKernelGGL((k_search<N, GP, false>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1]);
+            hipLaunchKernelGGL((k_search<N, GP, false>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1], c.dbg);
     }
 }
 

@@ -16,6 +16,13 @@
 #pragma once
 #include "az_net.h"
 
+#ifdef AZ_STAMPS
+#define KS_PARAM , unsigned long long *st
+#define KS_ARG , ks_ph
+#else
+#define KS_PARAM
+#define KS_ARG
+#endif
 #ifndef AZ_SEARCH_SKIP
 #define AZ_SEARCH_SKIP 0      // timing-only experiment builds (results are wrong): 1 = no FC, 2 = no tree step, 4 = no conv trunk
 #endif
@@ -53,8 +60,14 @@ template <int N, class PG, bool SYNTH>
 __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edge *rows, unsigned *path, GameLds &gs,
                                          const float *lg, const float *hid, const double *sq_lds, int rootN, int do_select,
                                          int pl, int slast, int netid, int game, int ply, const Plane &bX, const Plane &bO,
-                                         unsigned long long (&cnt)[4])
+                                         unsigned long long (&cnt)[4], float w2_l, float b2 KS_PARAM)
 {
+#ifdef AZ_STAMPS
+    unsigned long long st_t = __builtin_amdgcn_s_memtime();
+#define ST_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st[i] += t_ - st_t; st_t = t_; } while (0)
+#else
+#define ST_STAMP(i) do { } while (0)
+#endif
     typedef TreeGeo<N> G;
     static_assert(G::CPL == 1, "the LDS tree is for boards of at most 64 cells");
     const int kind_raw = gs.leaf_kind, depth0 = gs.depth, rows0 = gs.rows_used, leaf_last = gs.leaf_last;
@@ -91,12 +104,12 @@ __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edg
                 }
                 const float ssum = wave_sum_butterfly(part);
                 P = P / ssum;
+                ST_STAMP(10);        // softmax
                 // value tail: value_fc2 + tanh (net.py:70), one k-ordered fma chain
-                const float h_l = hid[lane], w2_l = d.v2w[netid][lane];
-                float acc = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 64; i++) acc = __builtin_fmaf(__shfl(h_l, i, 64), __shfl(w2_l, i, 64), acc);
-                v = az_tanhf(acc + d.v2b[netid][0]);
+                const float h_l = hid[lane];                      // w2_l, b2: value_fc2 of the game's net, read once per ply by the caller
+                const float acc = value_fc2_chain(h_l, w2_l);
+                v = az_tanhf(acc + b2);
+                ST_STAMP(11);        // value tail
             }
             if (kind == LEAF_ROOT && d.add_noise) {
                 // mcts.py:113-116; float32 multiply, float64 add, float32 store
@@ -122,6 +135,7 @@ __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edg
                 const unsigned pe = path[depth0 - 1];
                 if (lane == 0) rows[(pe >> 16) * PG::ROWE + (pe & 0xFFFFu)].child = (unsigned short)row;
             }
+            ST_STAMP(12);            // root noise, expand
         }
         if (kind != LEAF_ROOT) {
             // mcts.py:132-134,141,76-82: value w.r.t. the side to move at the leaf, backed up with alternating sign
@@ -139,6 +153,7 @@ __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edg
             cnt[3] += (unsigned long long)depth0;
         }
         wave_mem_sync();
+        ST_STAMP(13);                // backup
     }
     // ---------------- stage 2: selection (mcts.py:124-129) ----------------
     if (!do_select) {
@@ -164,8 +179,8 @@ __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edg
         wave_argmax(best, bi);
         const int a = __builtin_amdgcn_readfirstlane(bi);
         if (a < 0) { out_kind = LEAF_NONE; break; }
-        const int child = __shfl(bC, a, 64);
-        const int an = __shfl(bN, a, 64);
+        const int child = __builtin_amdgcn_readlane(bC, a);
+        const int an = __builtin_amdgcn_readlane(bN, a);
         if (lane == 0) path[depth] = ((unsigned)row << 16) | (unsigned)a;
         depth++;
         pl_set(me, a);                                        // games.py:79-81 place, flip player, remember action
@@ -184,6 +199,10 @@ __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edg
         gs.leaf_kind = out_kind;
         gs.depth = depth;
     }
+    ST_STAMP(14);                    // selection: `depth` levels
+#ifdef AZ_STAMPS
+    st[15] += (unsigned long long)depth;
+#endif
 }
 
 // policy_fc (net.py:65) and value_fc1 + ReLU (net.py:69) of the workgroup's GP boards in the canonical order of az_net.h
@@ -245,8 +264,17 @@ __device__ __forceinline__ void fc_mfma(const NetWeights &w, const float *featl,
 // One workgroup per CU (the LDS footprint allows no second one), i.e. two waves per SIMD: let the compiler use the
 // registers that leaves (256 VGPRs) instead of spilling for an occupancy the kernel can never have.
 template <int N, int GP, bool SYNTH>
-__global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_search(DevState d, NetWeights w0, NetWeights w1)
+__global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_search(DevState d, NetWeights w0, NetWeights w1, unsigned long long *dbg)
 {
+    // diagnostic builds only (-DAZ_STAMPS): s_memtime spent in each phase of the loop, summed over the ply, per workgroup
+    // (slots 0-9: the loop's phases on waves 0 and 1; 10-15: inside the tree step, see step_lds)
+#ifdef AZ_STAMPS
+    unsigned long long ks_ph[16] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    unsigned long long ks_t = __builtin_amdgcn_s_memtime();
+#define KS_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ks_ph[i] += t_ - ks_t; ks_t = t_; } while (0)
+#else
+#define KS_STAMP(i) do { } while (0)
+#endif
     typedef PersistGeo<N, GP> PG;
     typedef NetGeo<N> NG;
     typedef TreeGeo<N> TG;
@@ -260,7 +288,7 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
     __shared__ unsigned path_l[GP][PG::PATH];
     __shared__ GameLds games[GP];
     __shared__ double sq_lds[1026];                       // np.sqrt(N + 1e-8), N = 0..S+1 (S <= 1024)
-    __shared__ int any_eval, wg_net;
+    __shared__ int wg_net;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // GP x R x ROWE edges
     Edge *rows_all = reinterpret_cast<Edge *>(dyn_lds);
 
@@ -299,35 +327,43 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
     if (mine && lane == 0 && netid) atomicOr(&wg_net, 1);          // a workgroup's games share one net (arena: GP = 1)
     unsigned long long cnt[4] = {0ull, 0ull, 0ull, 0ull};
     unsigned long long cache_lookups = 0ull, cache_hits = 0ull;
+    // value_fc2 of the wave's game does not change over the ply: read once, not behind every evaluation
+    const float w2_l = (!SYNTH && mine) ? d.v2w[netid][lane] : 0.0f, b2 = (!SYNTH && mine) ? d.v2b[netid][0] : 0.0f;
     float *inA = lds, *inB = lds + 32 * PG::CS;
 
+    KS_STAMP(0);
     for (int idx = 0; idx <= S; idx++) {
-        if (tid == 0) any_eval = 0;
-        __syncthreads();
+        bool any_eval = false;                 // does a game of the workgroup wait for the net?  Every thread works it out for itself.
         if (!SYNTH) {
             // opt-in evaluation cache (az_set_eval_cache): the game's wave looks its pending leaf up in the table in HBM; a hit
             // puts the net's outputs for it into the LDS rows and the iteration needs no net for this game -- none at all when
             // every game of the workgroup hits
-            if (d.cache && mine && leaf_needs_net(games[wave].leaf_kind)) {
-                GameLds &gs = games[wave];
-                Plane lme, lopp;
+            if (d.cache) {
+                if (mine && leaf_needs_net(games[wave].leaf_kind)) {
+                    GameLds &gs = games[wave];
+                    Plane lme, lopp;
 #pragma unroll
-                for (int q = 0; q < 4; q++) { lme.w[q] = gs.leaf[q]; lopp.w[q] = gs.leaf[4 + q]; }
-                float cx[TG::CPL], ch;
-                const bool hit = cache_lookup<N>(d, lme, lopp, gs.leaf_last, netid, lane, cx, ch);
-                if (hit) {
+                    for (int q = 0; q < 4; q++) { lme.w[q] = gs.leaf[q]; lopp.w[q] = gs.leaf[4 + q]; }
+                    float cx[TG::CPL], ch;
+                    const bool hit = cache_lookup<N>(d, lme, lopp, gs.leaf_last, netid, lane, cx, ch);
+                    if (hit) {
 #pragma unroll
-                    for (int i = 0; i < TG::CPL; i++) logits_l[wave * PG::RW + lane + 64 * i] = cx[i];
-                    vhid_l[wave * 64 + lane] = ch;
-                    if (lane == 0) gs.leaf_kind = gs.leaf_kind == LEAF_ROOT ? LEAF_ROOT_HIT : LEAF_EXPAND_HIT;
+                        for (int i = 0; i < TG::CPL; i++) logits_l[wave * PG::RW + lane + 64 * i] = cx[i];
+                        vhid_l[wave * 64 + lane] = ch;
+                        if (lane == 0) gs.leaf_kind = gs.leaf_kind == LEAF_ROOT ? LEAF_ROOT_HIT : LEAF_EXPAND_HIT;
+                    }
+                    cache_lookups += 1ull;
+                    cache_hits += hit ? 1ull : 0ull;
                 }
-                cache_lookups += 1ull;
-                cache_hits += hit ? 1ull : 0ull;
+                __syncthreads();
             }
-            __syncthreads();
-            if (tid < GP && leaf_needs_net(games[tid].leaf_kind)) atomicOr(&any_eval, 1);
-            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < GP; g++) any_eval = any_eval || leaf_needs_net(games[g].leaf_kind);
         }
+        // without a net phase (whose barriers do it otherwise) this barrier keeps a game's wave from replacing its pending leaf
+        // while another wave still looks at it
+        if (SYNTH || !any_eval) __syncthreads();
+        KS_STAMP(1);
         if (!SYNTH && any_eval) {
             NetWeights w;                              // field-wise select: a reference to one of two argument structs would put both into scratch
             {
@@ -354,15 +390,19 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
                 }
             }
             __syncthreads();
+            KS_STAMP(2);
             if (!(AZ_SEARCH_SKIP & 4)) {
             conv_layer<PG, 4, 32, CONV_OUT_PACKED>(inB, inA, w.c1, w.c1b, wpos, cellof, wave, lane);
             __syncthreads();
             for (int i = tid; i < 3 * PG::CS; i += NTH) inB[i] = 0.0f;
             __syncthreads();
+            KS_STAMP(3);
             conv_layer<PG, 32, 64, CONV_OUT_PACKED>(inA, inB, w.c2, w.c2b, wpos, cellof, wave, lane);
             __syncthreads();
+            KS_STAMP(4);
             conv_layer<PG, 64, 128, CONV_OUT3>(inB, lds, w.c3, w.c3b, wpos, cellof, wave, lane);
             __syncthreads();
+            KS_STAMP(5);
             }
             // policy_conv (128->4) and value_conv (128->2), 1x1, into the LDS feature rows
             {
@@ -397,8 +437,10 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
                 }
             }
             __syncthreads();
+            KS_STAMP(6);
             if (!(AZ_SEARCH_SKIP & 1)) fc_mfma<PG, NG>(w, featl, logits_l, vhid_l, wave, lane);
             __syncthreads();
+            KS_STAMP(7);
             // a fresh evaluation is remembered (a game that hit had its rows recomputed beside its sibling's: the same floats)
             if (d.cache && mine && leaf_needs_net(games[wave].leaf_kind)) {
                 const GameLds &gs = games[wave];
@@ -415,8 +457,10 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
         if (mine && (!(AZ_SEARCH_SKIP & 2) || idx == S))
             step_lds<N, PG, SYNTH>(d, gb, lane, rows_all + (size_t)wave * d.R * PG::ROWE, path_l[wave], games[wave],
                                    logits_l + wave * PG::RW, vhid_l + wave * 64, sq_lds, idx, idx < S ? 1 : 0, pl, slast, netid,
-                                   game, ply, bX, bO, cnt);
+                                   game, ply, bX, bO, cnt, w2_l, b2 KS_ARG);
+        KS_STAMP(8);                 // the tree step of this wave's game (waves 0 .. GP - 1)
         __syncthreads();
+        KS_STAMP(9);                 // ... and the wait for the other game's
     }
     // ---- hand the root row to k_move (visit counts -> pi -> move), counters to the host ----
     if (mine) {
@@ -431,4 +475,8 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
             c[6] += cache_lookups; c[7] += cache_hits;
         }
     }
+#ifdef AZ_STAMPS
+    if (dbg && lane == 0 && wave < 2)
+        for (int i = 0; i < 16; i++) dbg[((size_t)blockIdx.x * 2 + wave) * 16 + i] = ks_ph[i];
+#endif
 }

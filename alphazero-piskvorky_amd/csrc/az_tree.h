@@ -431,9 +431,7 @@ __global__ __launch_bounds__(AZ_STEP_WAVES * 64) void k_step(DevState d, int roo
                 for (int i = 0; i < G::CPL; i++) P[i] = P[i] / ssum;
                 // value tail: value_fc2 + tanh (net.py:70), one k-ordered fma chain over the lane-held operands
                 const float w2_l = netid ? w2b : w2a;
-                float acc = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 64; i++) acc = __builtin_fmaf(__shfl(h_l, i, 64), __shfl(w2_l, i, 64), acc);
+                const float acc = value_fc2_chain(h_l, w2_l);
                 v = az_tanhf(acc + (netid ? b2b : b2a));
                 }
             }
@@ -518,8 +516,8 @@ __global__ __launch_bounds__(AZ_STEP_WAVES * 64) void k_step(DevState d, int roo
         const int a = __builtin_amdgcn_readfirstlane(bi);
         if (a < 0) { out_kind = LEAF_NONE; break; }            // unreachable for a non-terminal root; never index with -1
         // the lane that owns cell a (a & 63) holds its edge: the global best is also that lane's best
-        const int child = __shfl(bC, a & 63, 64);
-        const int an = __shfl(bN, a & 63, 64);
+        const int child = __builtin_amdgcn_readlane(bC, a & 63);
+        const int an = __builtin_amdgcn_readlane(bN, a & 63);
         if (lane == 0) path[depth] = ((unsigned)row << 16) | (unsigned)a;
         depth++;
         pl_set(me, a);                                        // games.py:79-81 place, flip player, remember action
@@ -657,9 +655,7 @@ __device__ __forceinline__ void vl_leaf_eval(const DevState &d, size_t it, const
     const float ssum = wave_sum_butterfly(part);
 #pragma unroll
     for (int i = 0; i < G::CPL; i++) P[i] = P[i] / ssum;
-    float acc = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 64; i++) acc = __builtin_fmaf(__shfl(h_l, i, 64), __shfl(w2_l, i, 64), acc);
+    const float acc = value_fc2_chain(h_l, w2_l);
     v = az_tanhf(acc + b2);
 }
 
@@ -787,8 +783,8 @@ __global__ __launch_bounds__(256) void k_step_vl(DevState d, int sims_done, int 
             wave_argmax(best, bi);
             const int a = __builtin_amdgcn_readfirstlane(bi);
             if (a < 0) { out_kind = LEAF_NONE; break; }
-            const int child = __shfl(bC, a & 63, 64);
-            const int an = __shfl(bN, a & 63, 64);
+            const int child = __builtin_amdgcn_readlane(bC, a & 63);
+            const int an = __builtin_amdgcn_readlane(bN, a & 63);
             if (lane == (a & 63)) {
                 Edge *e = rows + (size_t)row * G::RW + a;
                 e->N = (unsigned short)(e->N + (1 << EDGE_N_BITS));
