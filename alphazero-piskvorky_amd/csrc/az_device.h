@@ -172,6 +172,22 @@ __device__ __forceinline__ float value_fc2_chain(float h_l, float w2_l)
     return acc;
 }
 
+// the same chain with both operand vectors in LDS (16-byte aligned): every lane reads them with broadcast ds_read_b128
+__device__ __forceinline__ float value_fc2_chain_lds(const float *h, const float *w2)
+{
+    const float4 *h4 = reinterpret_cast<const float4 *>(h), *w4 = reinterpret_cast<const float4 *>(w2);
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const float4 a = h4[i], b = w4[i];
+        acc = __builtin_fmaf(a.x, b.x, acc);
+        acc = __builtin_fmaf(a.y, b.y, acc);
+        acc = __builtin_fmaf(a.z, b.z, acc);
+        acc = __builtin_fmaf(a.w, b.w, acc);
+    }
+    return acc;
+}
+
 // ---------------------------------------------------------------------------------------
 // bit-planed boards: 4 x u64 per plane (n*n <= 225 bits), cell j -> word j>>6, bit j&63
 // ---------------------------------------------------------------------------------------

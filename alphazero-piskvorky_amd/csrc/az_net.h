@@ -162,12 +162,43 @@ enum { CONV_OUT_PACKED = 0, CONV_OUT3 = 1, CONV_OUT_RESIDUAL = 2,    // RESIDUAL
 // (mt_cnt <= MTL); GO / out_pos_off: their packed output goes to an image of another geometry (the full board image in
 // global memory) at positions shifted by out_pos_off; O3S: row stride of the [co][cell] output of CONV_OUT3, whose columns
 // are counted from the workgroup's first tile.  The fused kernels use the defaults (all tiles, same geometry).
+// geometries that define TAP_FENCE = true keep the scheduler from moving instructions across tap boundaries (the persistent search
+// kernel: without it the weight loads of several taps are hoisted to the top of a layer and the kernel spills)
+template <class G, class = void> struct conv_tap_fence { static constexpr bool value = false; };
+template <class G> struct conv_tap_fence<G, std::enable_if_t<G::TAP_FENCE>> { static constexpr bool value = true; };
+
+// The first weight fragments of a layer (the ones conv_layer asks for at its top), requested by the caller ahead of the layer.
+// The persistent search kernel of the small boards does that one layer early: there a layer lasts 0.3-8 us, and the L2 round
+// trip in front of its first MFMA was a visible part of it.  Same registers, same values: results cannot change.
+template <int CIN, int NT>
+struct ConvPre {
+    static constexpr int NTW = (AZ_NTW <= NT) ? AZ_NTW : NT;
+    static constexpr int NF = CIN == 4 ? 3 : CIN / 16;       // float4 fragments per channel tile: conv1's whole weights, one tap's otherwise
+    float4 bw[NTW][NF];
+};
+template <class G, int CIN, int COUT, int NTL = COUT / 16>
+__device__ __forceinline__ ConvPre<CIN, NTL> conv_prefetch(const float *__restrict__ wp, int wave, int lane, int nt_base = 0)
+{
+    typedef ConvPre<CIN, NTL> P;
+    constexpr int NG = NTL / P::NTW;
+    constexpr int KS4 = (9 * (CIN / 4) + 3) / 4;
+    const int ng = wave % NG;
+    P r;
+#pragma unroll
+    for (int t = 0; t < P::NTW; t++) {
+        const float4 *w4 = reinterpret_cast<const float4 *>(wp) + (size_t)(nt_base + ng * P::NTW + t) * KS4 * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < P::NF; j++) r.bw[t][j] = w4[(size_t)j * 64];
+    }
+    return r;
+}
+
 template <class G, int CIN, int COUT, int MODE, int NTL = COUT / 16, int MTL = G::MT, class GO = G, int O3S = G::CS3>
 __device__ __forceinline__ void conv_layer(const float *in, float *out, const float *__restrict__ wp,
                                            const float *__restrict__ bias, const unsigned short *wpos,
                                            const unsigned short *cellof, int wave, int lane, int nt_base = 0,
                                            int mt_base = 0, int mt_cnt = MTL, int out_pos_off = 0, const float *res = nullptr,
-                                           unsigned long long *lst = nullptr)
+                                           unsigned long long *lst = nullptr, const ConvPre<CIN, NTL> *pre = nullptr)
 {
     // diagnostic builds only (-DAZ_STAMPS): per-wave time stamps of a layer's phases into lst[wave * 4 + k]
 #ifdef AZ_STAMPS
@@ -225,7 +256,9 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
         float bk[NTW][12];
 #pragma unroll
         for (int t = 0; t < NTW; t++) {
-            float4 b0 = wp4[t][0], b1 = wp4[t][64], b2 = wp4[t][128];
+            float4 b0, b1, b2;
+            if (pre) { b0 = pre->bw[t][0]; b1 = pre->bw[t][1]; b2 = pre->bw[t][2]; }
+            else { b0 = wp4[t][0]; b1 = wp4[t][64]; b2 = wp4[t][128]; }
             const float tmp[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
 #pragma unroll
             for (int j = 0; j < 12; j++) bk[t][j] = tmp[j];
@@ -261,7 +294,7 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
 #pragma unroll
         for (int t = 0; t < NTW; t++)
 #pragma unroll
-            for (int j = 0; j < NQ; j++) bw[t][j] = wp4[t][(size_t)j * 64];
+            for (int j = 0; j < NQ; j++) bw[t][j] = pre ? pre->bw[t][j] : wp4[t][(size_t)j * 64];
 #pragma unroll
         for (int i = 0; i < MTW; i++) a0[i] = in4[ra[i]];
         // AZ_UNROLL_TAPS: the nine taps unrolled, so that every fragment address is the tile's base register + a constant (the
@@ -275,6 +308,7 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
 #endif
         for (int tap = 0; tap < 9; tap++) {
             const int tn = tap + 1 < 9 ? tap + 1 : tap;
+            if constexpr (conv_tap_fence<G>::value) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < NTW; t++)
 #pragma unroll

@@ -35,7 +35,9 @@ struct PersistGeo {
     static constexpr bool ROWT = false;
     static constexpr int MT = (M + 15) / 16, MR = MT * 16;
     static constexpr int CS = up16(G * PP);
-    static constexpr int CS3 = up16(MR);
+    // row stride of the conv3 image [co][cell]: 16 mod 32, so that the four k-rows the head convs read with one instruction
+    // (channels q, q + 1, q + 2, q + 3 of a group: q x CS3 floats apart) fall into different LDS banks
+    static constexpr int CS3 = up16(MR) % 32 == 0 ? up16(MR) + 16 : up16(MR);
     static constexpr int LDSF = (96 * CS > 128 * CS3) ? 96 * CS : 128 * CS3;
     static constexpr int RW = ((nn + 63) / 64) * 64;
     static constexpr int NW = AZ_NW;
@@ -43,8 +45,6 @@ struct PersistGeo {
     static constexpr int FROW = (((PC + VC) * nn + 3) / 4) * 4;
     static constexpr int PATH = nn + 1;
     static constexpr int ROWE = nn;                                // edges per tree row in LDS (no padding to 64)
-    // static LDS of the kernel besides the tree rows (bytes), for the host's fit test
-    static constexpr int STATIC_BYTES = LDSF * 4 + MR * 4 + G * (FROW + RW + 64) * 4 + G * (PATH * 4 + 64 + 32) + 1024 * 8 + 64 + 256;
 };
 
 // LDS-resident search state of one game
@@ -60,7 +60,7 @@ template <int N, class PG, bool SYNTH>
 __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edge *rows, unsigned *path, GameLds &gs,
                                          const float *lg, const float *hid, const double *sq_lds, int rootN, int do_select,
                                          int pl, int slast, int netid, int game, int ply, const Plane &bX, const Plane &bO,
-                                         unsigned long long (&cnt)[4], float w2_l, float b2 KS_PARAM)
+                                         unsigned long long (&cnt)[4], const float *w2, float b2 KS_PARAM)
 {
 #ifdef AZ_STAMPS
     unsigned long long st_t = __builtin_amdgcn_s_memtime();
@@ -106,8 +106,7 @@ __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edg
                 P = P / ssum;
                 ST_STAMP(10);        // softmax
                 // value tail: value_fc2 + tanh (net.py:70), one k-ordered fma chain
-                const float h_l = hid[lane];                      // w2_l, b2: value_fc2 of the game's net, read once per ply by the caller
-                const float acc = value_fc2_chain(h_l, w2_l);
+                const float acc = value_fc2_chain_lds(hid, w2);    // w2, b2: value_fc2 of the game's net, put into LDS / a register once per ply
                 v = az_tanhf(acc + b2);
                 ST_STAMP(11);        // value tail
             }
@@ -176,7 +175,9 @@ __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edg
             best = Q + ((d.c_puct * (double)e.P) * sq) / (double)(1 + (int)e.N);
             bi = lane; bN = e.N; bC = e.child;
         }
+        ST_STAMP(16);                // one level: row read, PUCT scores
         wave_argmax(best, bi);
+        ST_STAMP(17);                // ... argmax
         const int a = __builtin_amdgcn_readfirstlane(bi);
         if (a < 0) { out_kind = LEAF_NONE; break; }
         const int child = __builtin_amdgcn_readlane(bC, a);
@@ -191,6 +192,7 @@ __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edg
         if (child == 0) { out_kind = LEAF_EXPAND; break; }    // mcts.py:127 node.is_leaf()
         npar = an;
         row = child;
+        ST_STAMP(18);                // ... move, terminal tests (of the levels that go on)
     }
     if (lane == 0) {
 #pragma unroll
@@ -210,26 +212,43 @@ __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edg
 // chains do not wait for each other), combined as ((p0 + p1) + (p2 + p3)) + bias.  Board rows beyond GP are zeros from
 // registers; the weight fragments of a tile (4 QG groups) are requested up front from L2; the feature rows are read from
 // LDS: featl row = [policy inputs | zeros up to 64 QGP][value inputs | zeros up to 64 QGV], stride NG::FSTR.
+template <class NG>
+struct FcPre {
+    float4 bw[4][NG::QGMAX];       // the wave's tile: weight fragments of its four chains
+    float bias;                    // bias of the lane's output
+};
+// the loads of fc_mfma, issued by the caller a phase early so that their L2 round trip is over when the FC phase starts
 template <class PG, class NG>
-__device__ __forceinline__ void fc_mfma(const NetWeights &w, const float *featl, float *logits_l, float *vhid_l, int wave, int lane)
+__device__ __forceinline__ FcPre<NG> fc_prefetch(const NetWeights &w, int wave, int lane)
+{
+    FcPre<NG> r;
+    const int tile = wave < NG::NTP + 4 ? wave : 0;
+    const bool is_pol = tile < NG::NTP;
+    const int QG = is_pol ? NG::QGP : NG::QGV;
+    const float4 *wp4 = reinterpret_cast<const float4 *>(is_pol ? w.pf : w.vf) +
+                        (size_t)(is_pol ? tile : tile - NG::NTP) * 4 * QG * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int j = 0; j < NG::QGMAX; j++) r.bw[c][j] = j < QG ? wp4[(size_t)(c * QG + j) * 64] : float4{0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15;
+    const int j = tile * 16 + r16, i = (tile - NG::NTP) * 16 + r16;
+    r.bias = is_pol ? (j < NG::nn ? w.pfb[j] : 0.0f) : w.vfb[i];
+    return r;
+}
+template <class PG, class NG>
+__device__ __forceinline__ void fc_mfma(const FcPre<NG> &pre, const float *featl, float *logits_l, float *vhid_l, int wave, int lane)
 {
     const int tile = wave;
     if (tile >= NG::NTP + 4) return;
     const int q = lane >> 4, r16 = lane & 15;
     const bool is_pol = tile < NG::NTP;
     const int QG = is_pol ? NG::QGP : NG::QGV;
-    const float4 *wp4 = reinterpret_cast<const float4 *>(is_pol ? w.pf : w.vf) +
-                        (size_t)(is_pol ? tile : tile - NG::NTP) * 4 * QG * 64 + lane;
     const bool row_ok = r16 < PG::G;
     const float *ip = featl + (row_ok ? r16 : 0) * NG::FSTR + (is_pol ? 0 : NG::VOFFL) + q;
     f32x4 acc[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float4 bw[4][NG::QGMAX];
-#pragma unroll
-    for (int c = 0; c < 4; c++)
-#pragma unroll
-        for (int j = 0; j < NG::QGMAX; j++) bw[c][j] = j < QG ? wp4[(size_t)(c * QG + j) * 64] : float4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NG::QGMAX; j++)
         if (j < QG) {
@@ -241,8 +260,10 @@ __device__ __forceinline__ void fc_mfma(const NetWeights &w, const float *featl,
 #pragma unroll
             for (int e = 0; e < 4; e++)
 #pragma unroll
-                for (int c = 0; c < 4; c++)
-                    acc[c] = mfma4(a[c][e], e == 0 ? bw[c][j].x : e == 1 ? bw[c][j].y : e == 2 ? bw[c][j].z : bw[c][j].w, acc[c]);
+                for (int c = 0; c < 4; c++) {
+                    const float4 bv = pre.bw[c][j];
+                    acc[c] = mfma4(a[c][e], e == 0 ? bv.x : e == 1 ? bv.y : e == 2 ? bv.z : bv.w, acc[c]);
+                }
         }
 #pragma unroll
     for (int rg = 0; rg < 4; rg++) {
@@ -251,10 +272,10 @@ __device__ __forceinline__ void fc_mfma(const NetWeights &w, const float *featl,
             const float r = (acc[0][rg] + acc[1][rg]) + (acc[2][rg] + acc[3][rg]);
             if (is_pol) {
                 const int j = tile * 16 + r16;
-                if (j < NG::nn) logits_l[g * PG::RW + j] = r + w.pfb[j];
+                if (j < NG::nn) logits_l[g * PG::RW + j] = r + pre.bias;
             } else {
                 const int i = (tile - NG::NTP) * 16 + r16;
-                const float v = r + w.vfb[i];
+                const float v = r + pre.bias;
                 vhid_l[g * 64 + i] = v > 0.0f ? v : 0.0f;
             }
         }
@@ -267,9 +288,10 @@ template <int N, int GP, bool SYNTH>
 __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_search(DevState d, NetWeights w0, NetWeights w1, unsigned long long *dbg)
 {
     // diagnostic builds only (-DAZ_STAMPS): s_memtime spent in each phase of the loop, summed over the ply, per workgroup
-    // (slots 0-9: the loop's phases on waves 0 and 1; 10-15: inside the tree step, see step_lds)
+    // (slots 0-9: the loop's phases on waves 0 and 1; 10-18: inside the tree step, see step_lds)
 #ifdef AZ_STAMPS
-    unsigned long long ks_ph[16] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    unsigned long long ks_ph[24];
+    for (int i = 0; i < 24; i++) ks_ph[i] = 0ull;
     unsigned long long ks_t = __builtin_amdgcn_s_memtime();
 #define KS_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ks_ph[i] += t_ - ks_t; ks_t = t_; } while (0)
 #else
@@ -279,12 +301,18 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
     typedef NetGeo<N> NG;
     typedef TreeGeo<N> TG;
     constexpr int NTH = AZ_NW * 64;
+    static_assert(NTH == 512, "hd_lds is filled by one float4 per thread");
     __shared__ __attribute__((aligned(16))) float lds[PG::LDSF];
     __shared__ unsigned short wpos[PG::MR];
     __shared__ unsigned short cellof[PG::MR];
+    __shared__ __attribute__((aligned(16))) float planes[4 * PG::CS];        // the encoded leaves [mover | opponent | last move | zeros][padded position]
+    __shared__ unsigned short cell_at[PG::CS];                               // game-major cell of a padded position, 0xFFFF = padding
     __shared__ __attribute__((aligned(16))) float featl[GP * NG::FSTR];       // head-conv outputs: [policy inputs | zeros][value inputs | zeros] per board (fc_mfma)
     __shared__ float logits_l[GP * PG::RW];
-    __shared__ float vhid_l[GP * 64];
+    __shared__ __attribute__((aligned(16))) float vhid_l[GP * 64];
+    __shared__ __attribute__((aligned(16))) float4 hd_lds[8 * 64];           // the head convs' weight fragments (read from L2 once per ply)
+    __shared__ float hdb_lds[8];
+    __shared__ __attribute__((aligned(16))) float w2_lds[GP * 64];           // value_fc2 weights of each game's net
     __shared__ unsigned path_l[GP][PG::PATH];
     __shared__ GameLds games[GP];
     __shared__ double sq_lds[1026];                       // np.sqrt(N + 1e-8), N = 0..S+1 (S <= 1024)
@@ -298,6 +326,17 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
     const int S = d.S;
     for (int i = tid; i < S + 2; i += NTH) sq_lds[i] = d.sqrt_table[i];
     for (int i = tid; i < GP * NG::FSTR; i += NTH) featl[i] = 0.0f;
+    for (int i = tid; i < PG::CS; i += NTH) {
+        const int g = i / PG::PP, pp = i - g * PG::PP, r = pp / PG::PW - 1, c = pp % PG::PW - 1;
+        cell_at[i] = (unsigned short)((g < GP && r >= 0 && r < N && c >= 0 && c < N) ? g * PG::nn + r * N + c : 0xFFFF);
+        planes[3 * PG::CS + i] = 0.0f;
+    }
+    // The padding ring of the two activation images is zero and stays zero: the layers write cells only.  What destroys it is
+    // conv3's [co][cell] image on top of them; the workgroup clears that again while the FC phase waits for its MFMA chains.
+    {
+        float4 *z = reinterpret_cast<float4 *>(lds);
+        for (int i = tid; i < (96 * PG::CS) / 4; i += NTH) z[i] = float4{0.f, 0.f, 0.f, 0.f};
+    }
     // tile tables (constant over the ply)
     for (int m = tid; m < PG::MR; m += NTH) {
         const int g = m / PG::nn, p = m - g * PG::nn, r = p / N, c = p - r * N;
@@ -325,10 +364,17 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
     if (tid == 0) wg_net = 0;
     __syncthreads();
     if (mine && lane == 0 && netid) atomicOr(&wg_net, 1);          // a workgroup's games share one net (arena: GP = 1)
+    __syncthreads();
+    if (!SYNTH) {                      // the head convs' weights stay in LDS for the ply (their L2 round trip sat between conv3 and the heads)
+        const bool o = wg_net != 0;
+        hd_lds[tid] = reinterpret_cast<const float4 *>(o ? w1.hd : w0.hd)[tid];          // 8 k-groups x 64 lanes = the 512 threads
+        if (tid < 8) hdb_lds[tid] = tid < 6 ? (o ? w1.hdb : w0.hdb)[tid] : 0.0f;
+    }
     unsigned long long cnt[4] = {0ull, 0ull, 0ull, 0ull};
     unsigned long long cache_lookups = 0ull, cache_hits = 0ull;
     // value_fc2 of the wave's game does not change over the ply: read once, not behind every evaluation
-    const float w2_l = (!SYNTH && mine) ? d.v2w[netid][lane] : 0.0f, b2 = (!SYNTH && mine) ? d.v2b[netid][0] : 0.0f;
+    const float b2 = (!SYNTH && mine) ? d.v2b[netid][0] : 0.0f;
+    if (!SYNTH && mine) w2_lds[wave * 64 + lane] = d.v2w[netid][lane];        // read by the same wave only: no barrier needed beyond the loop's
     float *inA = lds, *inB = lds + 32 * PG::CS;
 
     KS_STAMP(0);
@@ -372,45 +418,41 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
                 w.pf = o ? w1.pf : w0.pf; w.vf = o ? w1.vf : w0.vf; w.c1b = o ? w1.c1b : w0.c1b; w.c2b = o ? w1.c2b : w0.c2b;
                 w.c3b = o ? w1.c3b : w0.c3b; w.hdb = o ? w1.hdb : w0.hdb; w.pfb = o ? w1.pfb : w0.pfb; w.vfb = o ? w1.vfb : w0.vfb;
             }
+            const ConvPre<32, 4> pre2 = conv_prefetch<PG, 32, 64>(w.c2, wave, lane);     // conv2's first weights: asked for three phases early
             // ---- leaf encode + conv trunk, as trunk_group (az_net.h) on the LDS-resident leaves ----
-            {
-                float4 *z = reinterpret_cast<float4 *>(lds);
-                for (int i = tid; i < (96 * PG::CS) / 4; i += NTH) z[i] = float4{0.f, 0.f, 0.f, 0.f};
-            }
-            __syncthreads();
-            for (int m = tid; m < PG::MR; m += NTH) {          // games.py:86-129 encode
-                const int cell = cellof[m];
+            for (int i = tid; i < 3 * PG::CS; i += NTH) {       // games.py:86-129 encode: every position of the three planes, padding = 0
+                const int c = i / PG::CS, pos = i - c * PG::CS;
+                const int cell = cell_at[pos];
+                float v = 0.0f;
                 if (cell != 0xFFFF) {
                     const int g = cell / PG::nn, p = cell - g * PG::nn;
                     const GameLds &gs = games[g];
-                    const int pos = wpos[m];
-                    if ((gs.leaf[p >> 6] >> (p & 63)) & 1ull) inB[pos] = 1.0f;
-                    if ((gs.leaf[4 + (p >> 6)] >> (p & 63)) & 1ull) inB[PG::CS + pos] = 1.0f;
-                    if (gs.leaf_last == p) inB[2 * PG::CS + pos] = 1.0f;
+                    v = c == 2 ? (gs.leaf_last == p ? 1.0f : 0.0f) : (float)((gs.leaf[4 * c + (p >> 6)] >> (p & 63)) & 1ull);
                 }
+                planes[i] = v;
             }
             __syncthreads();
             KS_STAMP(2);
             if (!(AZ_SEARCH_SKIP & 4)) {
-            conv_layer<PG, 4, 32, CONV_OUT_PACKED>(inB, inA, w.c1, w.c1b, wpos, cellof, wave, lane);
-            __syncthreads();
-            for (int i = tid; i < 3 * PG::CS; i += NTH) inB[i] = 0.0f;
+            conv_layer<PG, 4, 32, CONV_OUT_PACKED>(planes, inA, w.c1, w.c1b, wpos, cellof, wave, lane);
             __syncthreads();
             KS_STAMP(3);
-            conv_layer<PG, 32, 64, CONV_OUT_PACKED>(inA, inB, w.c2, w.c2b, wpos, cellof, wave, lane);
+            const ConvPre<64, 8> pre3 = conv_prefetch<PG, 64, 128>(w.c3, wave, lane);    // ... conv3's while conv2 runs
+            conv_layer<PG, 32, 64, CONV_OUT_PACKED>(inA, inB, w.c2, w.c2b, wpos, cellof, wave, lane, 0, 0, PG::MT, 0, nullptr, nullptr, &pre2);
             __syncthreads();
             KS_STAMP(4);
-            conv_layer<PG, 64, 128, CONV_OUT3>(inB, lds, w.c3, w.c3b, wpos, cellof, wave, lane);
+            conv_layer<PG, 64, 128, CONV_OUT3>(inB, lds, w.c3, w.c3b, wpos, cellof, wave, lane, 0, 0, PG::MT, 0, nullptr, nullptr, &pre3);
             __syncthreads();
             KS_STAMP(5);
             }
+            const FcPre<NG> fpre = fc_prefetch<PG, NG>(w, wave, lane);      // the FC weights are on their way during the head convs
             // policy_conv (128->4) and value_conv (128->2), 1x1, into the LDS feature rows
             {
                 const int q = lane >> 4, r16 = lane & 15;
-                const float4 *wp4 = reinterpret_cast<const float4 *>(w.hd) + lane;
+                const float4 *wp4 = hd_lds + lane;
                 float hb[4];
 #pragma unroll
-                for (int rg = 0; rg < 4; rg++) hb[rg] = (q * 4 + rg) < 6 ? w.hdb[q * 4 + rg] : 0.0f;
+                for (int rg = 0; rg < 4; rg++) hb[rg] = (q * 4 + rg) < 6 ? hdb_lds[q * 4 + rg] : 0.0f;
                 for (int mt = wave; mt < PG::MT; mt += AZ_NW) {
                     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
                     const float *ip = lds + q * PG::CS3 + mt * 16 + r16;
@@ -438,7 +480,11 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
             }
             __syncthreads();
             KS_STAMP(6);
-            if (!(AZ_SEARCH_SKIP & 1)) fc_mfma<PG, NG>(w, featl, logits_l, vhid_l, wave, lane);
+            {
+                float4 *z = reinterpret_cast<float4 *>(lds);
+                for (int i = tid; i < (96 * PG::CS) / 4; i += NTH) z[i] = float4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (!(AZ_SEARCH_SKIP & 1)) fc_mfma<PG, NG>(fpre, featl, logits_l, vhid_l, wave, lane);
             __syncthreads();
             KS_STAMP(7);
             // a fresh evaluation is remembered (a game that hit had its rows recomputed beside its sibling's: the same floats)
@@ -457,7 +503,7 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
         if (mine && (!(AZ_SEARCH_SKIP & 2) || idx == S))
             step_lds<N, PG, SYNTH>(d, gb, lane, rows_all + (size_t)wave * d.R * PG::ROWE, path_l[wave], games[wave],
                                    logits_l + wave * PG::RW, vhid_l + wave * 64, sq_lds, idx, idx < S ? 1 : 0, pl, slast, netid,
-                                   game, ply, bX, bO, cnt, w2_l, b2 KS_ARG);
+                                   game, ply, bX, bO, cnt, w2_lds + wave * 64, b2 KS_ARG);
         KS_STAMP(8);                 // the tree step of this wave's game (waves 0 .. GP - 1)
         __syncthreads();
         KS_STAMP(9);                 // ... and the wait for the other game's
@@ -477,6 +523,6 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
     }
 #ifdef AZ_STAMPS
     if (dbg && lane == 0 && wave < 2)
-        for (int i = 0; i < 16; i++) dbg[((size_t)blockIdx.x * 2 + wave) * 16 + i] = ks_ph[i];
+        for (int i = 0; i < 24; i++) dbg[((size_t)blockIdx.x * 2 + wave) * 32 + i] = ks_ph[i];
 #endif
 }

@@ -16,9 +16,9 @@ e.load_weights(synthetic_state_dict(n), 0)
 e.selfplay_begin(B, seed0=1)
 e.selfplay_step(3)           # the third ply's stamps: every game still running, clocks warm
 nwg = B // 2
-buf = np.zeros((nwg * 2, 16), np.uint64)
-assert _capi.lib().az_debug_stamps(e.h, buf.ctypes.data_as(C.c_void_p), nwg * 2) == 0
-t = buf[:, :16].astype(np.float64).reshape(nwg, 2, 16)
+buf = np.zeros((nwg * 2, 32), np.uint64)
+assert _capi.lib().az_debug_stamps(e.h, buf.ctypes.data_as(C.c_void_p), nwg * 4) == 0
+t = buf[:, :24].astype(np.float64).reshape(nwg, 2, 24)
 names = ["kernel prologue", "iteration head (any_eval, 2-3 barriers)", "zero-fill + encode", "conv1 (+ plane re-zero)", "conv2", "conv3",
          "head convs", "policy_fc / value_fc1", "tree step (own game)", "wait for the other game's tree step"]
 w0 = t[:, 0, :]
@@ -32,5 +32,7 @@ lv = w0[:, 15].mean() / (S + 1)
 print(f"inside the tree step (wave 0); selection descends {lv:.2f} levels per iteration on average:")
 for i, nm in enumerate(inner):
     print(f"  {nm:40s} {w0[:, 10 + i].mean() / (S + 1):9.1f}")
-print(f"  {'selection per level':40s} {w0[:, 14].mean() / max(w0[:, 15].mean(), 1):9.1f}")
+lvn = max(w0[:, 15].mean(), 1)
+print(f"  {'selection per level':40s} {w0[:, 14].mean() / lvn:9.1f}  (row read + PUCT {w0[:, 16].mean() / lvn:.1f}, argmax {w0[:, 17].mean() / lvn:.1f}, "
+      f"move + terminal tests of the levels that go on {w0[:, 18].mean() / lvn:.1f}; the rest is the last level's exit and the leaf's hand-over)")
 e.close()
