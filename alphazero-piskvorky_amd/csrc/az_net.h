@@ -162,11 +162,6 @@ enum { CONV_OUT_PACKED = 0, CONV_OUT3 = 1, CONV_OUT_RESIDUAL = 2,    // RESIDUAL
 // (mt_cnt <= MTL); GO / out_pos_off: their packed output goes to an image of another geometry (the full board image in
 // global memory) at positions shifted by out_pos_off; O3S: row stride of the [co][cell] output of CONV_OUT3, whose columns
 // are counted from the workgroup's first tile.  The fused kernels use the defaults (all tiles, same geometry).
-// geometries that define TAP_FENCE = true keep the scheduler from moving instructions across tap boundaries (the persistent search
-// kernel: without it the weight loads of several taps are hoisted to the top of a layer and the kernel spills)
-template <class G, class = void> struct conv_tap_fence { static constexpr bool value = false; };
-template <class G> struct conv_tap_fence<G, std::enable_if_t<G::TAP_FENCE>> { static constexpr bool value = true; };
-
 // The first weight fragments of a layer (the ones conv_layer asks for at its top), requested by the caller ahead of the layer.
 // The persistent search kernel of the small boards does that one layer early: there a layer lasts 0.3-8 us, and the L2 round
 // trip in front of its first MFMA was a visible part of it.  Same registers, same values: results cannot change.
@@ -308,7 +303,6 @@ __device__ __forceinline__ void conv_layer(const float *in, float *out, const fl
 #endif
         for (int tap = 0; tap < 9; tap++) {
             const int tn = tap + 1 < 9 ? tap + 1 : tap;
-            if constexpr (conv_tap_fence<G>::value) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < NTW; t++)
 #pragma unroll
