@@ -5,8 +5,11 @@
 // k_step -- and on small boards the ~5 us between dependent dispatches is a third of a simulation's time.  Here a
 // workgroup of 8 waves owns GP games for a whole ply and loops S + 1 times over
 //     encode -> conv1 -> conv2 -> conv3 -> 1x1 heads        (all 8 waves, MFMA, activations in LDS like k_trunk)
-//     policy_fc / value_fc1                                  (one k-ordered fmaf chain per output and thread)
+//     policy_fc / value_fc1                                  (one 16-output tile per wave on the MFMA, the canonical four k-chains)
 //     softmax + value tail, expand, backup, PUCT select      (one wavefront per game, like k_step)
+// What a phase needs from L2 is asked for before the phase in front of it (the first weight fragments of conv2 / conv3, the FC
+// weights) or lives in LDS for the whole ply (the head convs' weights, value_fc2); the images' padding ring is cleared while the
+// FC phase waits for its MFMA chains.  tools/stamps_search.py shows the cycles of every phase.
 // without leaving the CU: the node array -- one row of n*n 16-byte edges per expanded node, (S + 1) rows per game --
 // lives in LDS next to the activations, so a level of the descent is one ds_read_b128 per lane instead of an L2 round
 // trip, and nothing but the weights (L2 hits), the root's Dirichlet noise and the final root row crosses the CU boundary.
