@@ -1746,7 +1746,6 @@ extern "C" int az_set_eval_cache(az_engine *e, int64_t entries)
     if (!e) return AZ_ERR_INVALID;
     if (e->run.open) return fail(e, AZ_ERR_STATE, "az_set_eval_cache: an episode is open");
     if (entries < 0 || entries > ((int64_t)1 << 26)) return fail(e, AZ_ERR_INVALID, "cache entries must be 0 (off) .. 2^26");
-    if (entries > 0 && e->leaf_symmetry) return fail(e, AZ_ERR_INVALID, "the evaluation cache and random-symmetry leaf evaluation cannot be combined");
     DEVICE_GUARD(e);
     if (entries == 0) {
         dev_free(e->cache);
@@ -1770,8 +1769,8 @@ extern "C" int az_set_leaf_symmetry(az_engine *e, int on)
 {
     if (!e) return AZ_ERR_INVALID;
     if (e->run.open) return fail(e, AZ_ERR_STATE, "az_set_leaf_symmetry: an episode is open");
-    if (on && (e->reuse || e->cache.p))
-        return fail(e, AZ_ERR_INVALID, "random-symmetry leaf evaluation cannot be combined with subtree reuse or the evaluation cache");
+    if (on && e->reuse)
+        return fail(e, AZ_ERR_INVALID, "random-symmetry leaf evaluation cannot be combined with subtree reuse");
     if (on && e->cfg.eval_kind != AZ_EVAL_NET) return fail(e, AZ_ERR_INVALID, "random-symmetry leaf evaluation needs the net evaluator");
     e->leaf_symmetry = on ? 1 : 0;
     for (Lane &L : e->lanes) L.d.leaf_sym = on ? (int *)L.leaf_sym.p : nullptr;

@@ -195,6 +195,27 @@ __device__ __forceinline__ void cache_insert(const DevState &d, const Plane &me,
     ent[CACHE_HDR + G::RW + lane] = h;
 }
 
+// With random-symmetry leaf evaluation (az_set_leaf_symmetry) the net's outputs depend on the symmetry it was shown, so the
+// symmetry is part of the key (folded into the net field), and a hit lands in the logits row the way the net would have written
+// it -- in image coordinates, board cell j at image cell sym_src(t^-1, j) -- because the tree step maps every row back.
+__device__ __forceinline__ int cache_net_key(int net, int sym) { return net | (sym << 1); }
+template <int N>
+__device__ __forceinline__ void cache_hit_store(float *lg, const float (&cx)[TreeGeo<N>::CPL], int lane, bool sym_on, int sym)
+{
+    typedef TreeGeo<N> G;
+    if (sym_on) {
+        const int ti = sym_inverse(sym);
+#pragma unroll
+        for (int i = 0; i < G::CPL; i++) {
+            const int j = lane + 64 * i, r = j / N;
+            if (j < G::nn) lg[sym_src(ti, r, j - r * N, N)] = cx[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < G::CPL; i++) lg[lane + 64 * i] = cx[i];
+    }
+}
+
 // controller.py:49 softmax over all n^2 logits (no legality mask) in the canonical wave order, and the
 // value tail value_fc2 + tanh (net.py:70) as one k-ordered fma chain.  P[i] is the prior of cell lane+64*i.
 template <int N>
@@ -400,7 +421,7 @@ __global__ __launch_bounds__(AZ_STEP_WAVES * 64) void k_step(DevState d, int roo
                     float xc[G::CPL];
 #pragma unroll
                     for (int i = 0; i < G::CPL; i++) xc[i] = lane + 64 * i < G::nn ? x[i] : 0.0f;
-                    cache_insert<N>(d, lme, lopp, leaf_last, netid, lane, xc, h_l);
+                    cache_insert<N>(d, lme, lopp, leaf_last, cache_net_key(netid, d.leaf_sym ? d.leaf_sym[bb] : 0), lane, xc, h_l);
                 }
                 if (d.ext_eval) {
                     // the evaluator lives outside the engine (policy_value_fn seam, mcts.py:87-93,109,137): the row holds
@@ -532,10 +553,10 @@ __global__ __launch_bounds__(AZ_STEP_WAVES * 64) void k_step(DevState d, int roo
     if (!SYNTH && d.cache && out_kind == LEAF_EXPAND) {
         // the leaf's evaluation may be known already (an earlier ply's search, another game, a transposition)
         float cx[G::CPL], ch;
-        const bool hit = cache_lookup<N>(d, me, opp, last, netid, lane, cx, ch);
+        const int sym = d.leaf_sym ? leaf_sym_of((int)(d.game_key0 + (unsigned)game), ply, rootN + 1) : 0;     // as stored below
+        const bool hit = cache_lookup<N>(d, me, opp, last, cache_net_key(netid, sym), lane, cx, ch);
         if (hit) {
-#pragma unroll
-            for (int i = 0; i < G::CPL; i++) d.logits[(size_t)b * G::RW + lane + 64 * i] = cx[i];
+            cache_hit_store<N>(d.logits + (size_t)b * G::RW, cx, lane, d.leaf_sym != nullptr, sym);
             d.vhid[(size_t)b * 64 + lane] = ch;
             out_kind = LEAF_EXPAND_HIT;
         }
@@ -566,10 +587,10 @@ __global__ __launch_bounds__(256) void k_root_cache(DevState d)
     if (d.leaf_kind[it] != LEAF_ROOT) return;
     const Plane me = pl_load(d.leaf + it * 8), opp = pl_load(d.leaf + it * 8 + 4);
     float cx[G::CPL], ch;
-    const bool hit = cache_lookup<N>(d, me, opp, d.leaf_last[it], d.s_net[b], lane, cx, ch);
+    const int sym = d.leaf_sym ? d.leaf_sym[it] : 0;
+    const bool hit = cache_lookup<N>(d, me, opp, d.leaf_last[it], cache_net_key(d.s_net[b], sym), lane, cx, ch);
     if (hit) {
-#pragma unroll
-        for (int i = 0; i < G::CPL; i++) d.logits[it * G::RW + lane + 64 * i] = cx[i];
+        cache_hit_store<N>(d.logits + it * G::RW, cx, lane, d.leaf_sym != nullptr, sym);
         d.vhid[it * 64 + lane] = ch;
     }
     if (lane == 0) {
@@ -635,7 +656,7 @@ __device__ __forceinline__ void vl_leaf_eval(const DevState &d, size_t it, const
     const float h_l = d.vhid[it * 64 + lane];
     const float w2_l = d.v2w[netid][lane];
     const float b2 = d.v2b[netid][0];
-    if (d.cache && fresh) cache_insert<N>(d, lme, lopp, leaf_last, netid, lane, x, h_l);
+    if (d.cache && fresh) cache_insert<N>(d, lme, lopp, leaf_last, cache_net_key(netid, d.leaf_sym ? d.leaf_sym[it] : 0), lane, x, h_l);
     float mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < G::CPL; i++) {
@@ -812,10 +833,10 @@ __global__ __launch_bounds__(256) void k_step_vl(DevState d, int sims_done, int 
                 mark = leaf_edge;
                 if (!SYNTH && d.cache) {
                     float cx[G::CPL], ch;
-                    const bool hit = cache_lookup<N>(d, me, opp, last, netid, lane, cx, ch);
+                    const int sym = d.leaf_sym ? leaf_sym_of((int)(d.game_key0 + (unsigned)game), ply, sims_done + j + 1) : 0;
+                    const bool hit = cache_lookup<N>(d, me, opp, last, cache_net_key(netid, sym), lane, cx, ch);
                     if (hit) {
-#pragma unroll
-                        for (int i = 0; i < G::CPL; i++) d.logits[it * G::RW + lane + 64 * i] = cx[i];
+                        cache_hit_store<N>(d.logits + it * G::RW, cx, lane, d.leaf_sym != nullptr, sym);
                         d.vhid[it * 64 + lane] = ch;
                         out_kind = LEAF_EXPAND_HIT;
                     }

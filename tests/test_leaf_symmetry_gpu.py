@@ -93,9 +93,8 @@ def test_leaf_symmetry_with_the_emulated_trunk_and_rejected_combinations():
     c = e.selfplay(4, seed0=3, max_plies=5)
     assert c["simulations"] == S * c["plies"] and int(e.records()["visits"].sum()) == S * c["plies"]
     e.set_trunk_mode("f32")
-    for call in (lambda: e.set_subtree_reuse(True), lambda: e.set_eval_cache(1024)):
-        with pytest.raises(_capi.AzError):
-            call()
+    with pytest.raises(_capi.AzError):
+        e.set_subtree_reuse(True)
     e.close()
     s = az.Engine(5, 4, 8, 2, synthetic=True)
     with pytest.raises(_capi.AzError):
@@ -131,3 +130,39 @@ def test_leaf_symmetry_with_virtual_loss_batching_bit_exact_vs_oracle(n, k, S, G
             for key in ("actions", "boards", "visits", "pis"):
                 assert np.array_equal(rec[key][sl], r[key]), f"game {g}: {key} differs from the oracle (order {order})"
             off += Lg
+
+
+@pytest.mark.parametrize("n,k,S,G,slots,cut,L", [(5, 4, 60, 96, 32, 0, 1), (9, 5, 40, 24, 8, 8, 1), (5, 4, 40, 48, 16, 0, 4)])
+def test_leaf_symmetry_with_the_evaluation_cache(n, k, S, G, slots, cut, L):
+    """Round 3: the two opt-ins compose.  The net's outputs depend on the symmetry it was shown, so the symmetry is part of the
+    cache key, and a hit lands in the logits row in image coordinates like a fresh evaluation.  Records with the cache on are the
+    records with it off -- which are the oracle's (orc_cfg.leaf_sym) -- and the cache does hit (trained 5x5 weights)."""
+    seed0 = 4242
+    sd = weights_from_fixture(5, "ckpt_saved") if n == 5 else build_weights(n)
+    onet = orc.Net(n, sd)
+    out = []
+    for entries in (0, 1 << 16):
+        e = az.Engine(n, k, S, slots, log_table=orc.numpy_log_table(S))
+        e.load_weights(sd, 0)
+        if L > 1:
+            e.set_virtual_loss(L)
+        e.set_eval_cache(entries)
+        e.set_leaf_symmetry(True)
+        c = e.selfplay(G, seed0=seed0, max_plies=cut)
+        out.append((e.records(), e.games(), c))
+        e.close()
+    (r0, g0, c0), (r1, g1, c1) = out
+    for key in r0:
+        assert np.array_equal(r0[key], r1[key]), key
+    assert np.array_equal(g0[0], g1[0]) and np.array_equal(g0[1], g1[1])
+    assert c1["cache_lookups"] > 0 and c1["cache_hits"] > 0 and c0["cache_hits"] == 0
+    o = orc.Oracle(n, k, S, leaf_sym=True, virtual_loss=L) if L > 1 else orc.Oracle(n, k, S, leaf_sym=True)
+    off = 0
+    for g in range(3):
+        noise, us = orc.selfplay_tape(seed0 + g, n, maxply=cut or None)
+        r = o.selfplay_game(onet, noise, us, maxply=cut or None, game=seed0 + g)
+        Lg = int(g1[0][g]); sl = slice(off, off + Lg)
+        assert Lg == r["nply"]
+        for key in ("actions", "visits", "pis"):
+            assert np.array_equal(r1[key][sl], r[key]), f"game {g}: {key}"
+        off += Lg
