@@ -1695,7 +1695,6 @@ extern "C" int az_set_subtree_reuse(az_engine *e, int on)
     if (!e) return AZ_ERR_INVALID;
     if (e->run.open) return fail(e, AZ_ERR_STATE, "az_set_subtree_reuse: an episode is open");
     if (on && e->vl > 1) return fail(e, AZ_ERR_INVALID, "subtree reuse and virtual-loss batching cannot be combined");
-    if (on && e->leaf_symmetry) return fail(e, AZ_ERR_INVALID, "subtree reuse and random-symmetry leaf evaluation cannot be combined");
     if (on && e->R > REUSE_MAX_ROWS)
         return fail(e, AZ_ERR_INVALID, "subtree reuse supports at most %d simulations per move", REUSE_MAX_ROWS - 1);
     e->reuse = on ? 1 : 0;
@@ -1769,8 +1768,6 @@ extern "C" int az_set_leaf_symmetry(az_engine *e, int on)
 {
     if (!e) return AZ_ERR_INVALID;
     if (e->run.open) return fail(e, AZ_ERR_STATE, "az_set_leaf_symmetry: an episode is open");
-    if (on && e->reuse)
-        return fail(e, AZ_ERR_INVALID, "random-symmetry leaf evaluation cannot be combined with subtree reuse");
     if (on && e->cfg.eval_kind != AZ_EVAL_NET) return fail(e, AZ_ERR_INVALID, "random-symmetry leaf evaluation needs the net evaluator");
     e->leaf_symmetry = on ? 1 : 0;
     for (Lane &L : e->lanes) L.d.leaf_sym = on ? (int *)L.leaf_sym.p : nullptr;

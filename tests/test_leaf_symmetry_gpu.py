@@ -84,7 +84,7 @@ def test_single_search_and_arena_with_leaf_symmetry():
     e.close()
 
 
-def test_leaf_symmetry_with_the_emulated_trunk_and_rejected_combinations():
+def test_leaf_symmetry_with_the_emulated_trunk_and_rejected_evaluators():
     n, k, S = 9, 5, 40
     e = az.Engine(n, k, S, 4)
     e.load_weights(build_weights(n), 0)
@@ -93,8 +93,6 @@ def test_leaf_symmetry_with_the_emulated_trunk_and_rejected_combinations():
     c = e.selfplay(4, seed0=3, max_plies=5)
     assert c["simulations"] == S * c["plies"] and int(e.records()["visits"].sum()) == S * c["plies"]
     e.set_trunk_mode("f32")
-    with pytest.raises(_capi.AzError):
-        e.set_subtree_reuse(True)
     e.close()
     s = az.Engine(5, 4, 8, 2, synthetic=True)
     with pytest.raises(_capi.AzError):
@@ -165,4 +163,32 @@ def test_leaf_symmetry_with_the_evaluation_cache(n, k, S, G, slots, cut, L):
         assert Lg == r["nply"]
         for key in ("actions", "visits", "pis"):
             assert np.array_equal(r1[key][sl], r[key]), f"game {g}: {key}"
+        off += Lg
+
+
+@pytest.mark.parametrize("n,k,S,G,slots,cut", [(5, 4, 60, 24, 8, 0), (9, 5, 40, 6, 4, 10)])
+def test_leaf_symmetry_with_subtree_reuse_bit_exact_vs_oracle(n, k, S, G, slots, cut):
+    """Round 3: the two opt-ins compose without a new definition -- a retained root is not evaluated again, and simulation s
+    of its search is evaluation s + 1 whether the search starts at 0 or at the visits the root carried over.  Engine == oracle
+    (orc_cfg.reuse + orc_cfg.leaf_sym) bit for bit, and roots are in fact retained."""
+    seed0 = 5151
+    sd = weights_from_fixture(5, "ckpt_saved") if n == 5 else build_weights(n)
+    onet = orc.Net(n, sd)
+    e = az.Engine(n, k, S, slots, log_table=orc.numpy_log_table(S))
+    e.load_weights(sd, 0)
+    e.set_leaf_symmetry(True)
+    e.set_subtree_reuse(True)
+    c = e.selfplay(G, seed0=seed0, max_plies=cut)
+    rec = e.records(); nply, res = e.games()
+    e.close()
+    assert c["simulations"] < S * c["plies"]          # retained roots carried visits over
+    o = orc.Oracle(n, k, S, leaf_sym=True, reuse=True)
+    off = 0
+    for g in range(G):
+        noise, us = orc.selfplay_tape(seed0 + g, n, maxply=cut or None)
+        r = o.selfplay_game(onet, noise, us, maxply=cut or None, game=seed0 + g)
+        Lg = int(nply[g]); sl = slice(off, off + Lg)
+        assert Lg == r["nply"], f"game {g}"
+        for key in ("actions", "boards", "visits", "pis"):
+            assert np.array_equal(rec[key][sl], r[key]), f"game {g}: {key}"
         off += Lg
