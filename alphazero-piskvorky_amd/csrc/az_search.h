@@ -54,6 +54,7 @@ struct PersistGeo {
 struct GameLds {
     u64 leaf[8];           // mover-relative planes of the pending leaf
     int leaf_last, leaf_kind, depth, rows_used;
+    int sym;               // symmetry the net sees the pending leaf under (az_set_leaf_symmetry; 0 = as it is)
 };
 
 // the tree step of one game on LDS rows: k_step's two stages (az_tree.h) with the node array, the path and the evaluator
@@ -97,7 +98,15 @@ __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edg
                 v = (float)(vv - 256) / 256.0f;
             } else {
                 // controller.py:49 softmax over all n^2 logits (no legality mask), canonical wave order
-                const float x = lane < G::nn ? lg[lane] : -INFINITY;
+                float x = -INFINITY;
+                if (lane < G::nn) {
+                    if (d.leaf_sym) {       // the net saw the leaf under symmetry t: board cell j sits at image cell sym_src(t^-1, j)
+                        const int r = lane / N;
+                        x = lg[sym_src(sym_inverse(gs.sym), r, lane - r * N, N)];
+                    } else {
+                        x = lg[lane];
+                    }
+                }
                 const float mx = wave_max_f(x);
                 P = 0.0f;
                 float part = 0.0f;
@@ -203,6 +212,7 @@ __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edg
         gs.leaf_last = last;
         gs.leaf_kind = out_kind;
         gs.depth = depth;
+        if (d.leaf_sym) gs.sym = leaf_sym_of((int)(d.game_key0 + (unsigned)game), ply, rootN + 1);     // this leaf is evaluation rootN + 1 of the search (as k_step)
     }
     ST_STAMP(14);                    // selection: `depth` levels
 #ifdef AZ_STAMPS
@@ -360,6 +370,7 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
         const int kind = mine ? d.leaf_kind[gb] : LEAF_NONE;       // k_begin staged the root as the pending leaf
         for (int q = 0; q < 8; q++) gs.leaf[q] = mine ? d.leaf[(size_t)gb * 8 + q] : 0ull;
         gs.leaf_last = mine ? d.leaf_last[gb] : -1;
+        gs.sym = (mine && d.leaf_sym) ? d.leaf_sym[gb] : 0;          // k_begin: the root is evaluation 0
         gs.leaf_kind = kind == LEAF_ROOT ? LEAF_ROOT : LEAF_NONE;
         gs.depth = 0;
         gs.rows_used = 0;
@@ -394,10 +405,9 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
 #pragma unroll
                     for (int q = 0; q < 4; q++) { lme.w[q] = gs.leaf[q]; lopp.w[q] = gs.leaf[4 + q]; }
                     float cx[TG::CPL], ch;
-                    const bool hit = cache_lookup<N>(d, lme, lopp, gs.leaf_last, netid, lane, cx, ch);
+                    const bool hit = cache_lookup<N>(d, lme, lopp, gs.leaf_last, cache_net_key(netid, gs.sym), lane, cx, ch);
                     if (hit) {
-#pragma unroll
-                        for (int i = 0; i < TG::CPL; i++) logits_l[wave * PG::RW + lane + 64 * i] = cx[i];
+                        cache_hit_store<N>(logits_l + wave * PG::RW, cx, lane, d.leaf_sym != nullptr, gs.sym);
                         vhid_l[wave * 64 + lane] = ch;
                         if (lane == 0) gs.leaf_kind = gs.leaf_kind == LEAF_ROOT ? LEAF_ROOT_HIT : LEAF_EXPAND_HIT;
                     }
@@ -428,8 +438,10 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
                 const int cell = cell_at[pos];
                 float v = 0.0f;
                 if (cell != 0xFFFF) {
-                    const int g = cell / PG::nn, p = cell - g * PG::nn;
+                    const int g = cell / PG::nn, pi = cell - g * PG::nn;
                     const GameLds &gs = games[g];
+                    int p = pi;                                  // board cell whose stone the net sees at image cell pi
+                    if (d.leaf_sym) { const int r = pi / N; p = sym_src(gs.sym, r, pi - r * N, N); }
                     v = c == 2 ? (gs.leaf_last == p ? 1.0f : 0.0f) : (float)((gs.leaf[4 * c + (p >> 6)] >> (p & 63)) & 1ull);
                 }
                 planes[i] = v;
@@ -498,8 +510,11 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
                 for (int q = 0; q < 4; q++) { lme.w[q] = gs.leaf[q]; lopp.w[q] = gs.leaf[4 + q]; }
                 float cx[TG::CPL];
 #pragma unroll
-                for (int i = 0; i < TG::CPL; i++) cx[i] = lane + 64 * i < TG::nn ? logits_l[wave * PG::RW + lane + 64 * i] : 0.0f;
-                cache_insert<N>(d, lme, lopp, gs.leaf_last, netid, lane, cx, vhid_l[wave * 64 + lane]);
+                for (int i = 0; i < TG::CPL; i++) {         // entries hold the logits in board order, as k_step's
+                    const int j = lane + 64 * i, r = j / N;
+                    cx[i] = j < TG::nn ? logits_l[wave * PG::RW + (d.leaf_sym ? sym_src(sym_inverse(gs.sym), r, j - r * N, N) : j)] : 0.0f;
+                }
+                cache_insert<N>(d, lme, lopp, gs.leaf_last, cache_net_key(netid, gs.sym), lane, cx, vhid_l[wave * 64 + lane]);
             }
         }
         // ---- tree step: wave g works on game g ----

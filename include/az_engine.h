@@ -309,7 +309,7 @@ int az_set_eval_cache(az_engine *e, int64_t entries);
  * named by its seed, which a rank playing the id block [lo, hi) of a larger episode passes as seed0 + lo -- so runs are
  * reproducible and independent of slots, lanes and ranks (az_search / az_search_callback: key 0).  Visit counts differ from the reference's (its net always sees the position
  * unrotated); parity is against the oracle's restatement of this rule (orc_cfg.leaf_sym, "parity unpinned" by the
- * reference).  Lock-step pipeline only; combines with virtual-loss batching (simulation s of a batch is evaluation s + 1 like
+ * reference).  Lock-step pipeline and persistent search kernel alike; combines with virtual-loss batching (simulation s of a batch is evaluation s + 1 like
  * in the sequential loop), with the evaluation cache (the symmetry is part of the key: a hit is the evaluation under that
  * symmetry, records are unchanged) and with subtree reuse (a retained root is not evaluated again; simulation s stays
  * evaluation s + 1); az_search_callback evaluates positions as they are.  Not allowed while an episode is open. */

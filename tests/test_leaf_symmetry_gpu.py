@@ -29,13 +29,14 @@ def _nets(n, model):
                                                (9, 5, 24, 3, 5, "resnet")])
 def test_selfplay_with_leaf_symmetry_bit_exact_vs_oracle(n, k, S, G, cut, model, split, monkeypatch):
     monkeypatch.setenv("AZ_SPLIT_MAX", split)
+    monkeypatch.setenv("AZ_PERSIST", "0" if split == "0" else "1")        # 5x5: once on the lock-step pipeline, once in the persistent kernel
     seed0 = 7700
     sd, onet = _nets(n, model)
     e = az.Engine(n, k, S, 3, log_table=orc.numpy_log_table(S), model=model)       # fewer slots than games: refills included
     e.load_weights(sd, 0)
     e.set_leaf_symmetry(True)
     c = e.selfplay(G, seed0=seed0, max_plies=cut)
-    assert e.persistent() == 0            # the option runs on the lock-step pipeline
+    assert (e.persistent() > 0) == (n <= 7 and model == "plain" and split != "0")     # round 3: the persistent kernel knows the option too
     rec = e.records(); nply, res = e.games()
     o = orc.Oracle(n, k, S, leaf_sym=True)
     plain = orc.Oracle(n, k, S)
