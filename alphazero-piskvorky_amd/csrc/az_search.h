@@ -58,13 +58,13 @@ struct GameLds {
 };
 
 // the tree step of one game on LDS rows: k_step's two stages (az_tree.h) with the node array, the path and the evaluator
-// outputs in LDS.  One wavefront.  No subtree reuse on this path; an evaluation-cache hit (LEAF_*_HIT, set by k_search before the
+// outputs in LDS.  One wavefront.  Subtree reuse: k_search loads the retained rows and writes the whole tree back; an evaluation-cache hit (LEAF_*_HIT, set by k_search before the
 // net phase) is consumed exactly like the evaluation it stands for.
 template <int N, class PG, bool SYNTH>
 __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edge *rows, unsigned *path, GameLds &gs,
                                          const float *lg, const float *hid, const double *sq_lds, int rootN, int do_select,
                                          int pl, int slast, int netid, int game, int ply, const Plane &bX, const Plane &bO,
-                                         unsigned long long (&cnt)[4], const float *w2, float b2 KS_PARAM)
+                                         unsigned long long (&cnt)[4], const float *w2, float b2, int carried KS_PARAM)
 {
 #ifdef AZ_STAMPS
     unsigned long long st_t = __builtin_amdgcn_s_memtime();
@@ -80,7 +80,23 @@ __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edg
 #pragma unroll
     for (int q = 0; q < 4; q++) { lme.w[q] = gs.leaf[q]; lopp.w[q] = gs.leaf[4 + q]; }
     // ---------------- stage 1: evaluation -> expand -> backup ----------------
-    if (kind != LEAF_NONE) {
+    if (kind == LEAF_REUSE) {
+        // subtree reuse: the root kept from the previous ply (its rows were loaded by k_search) is not evaluated again; only the
+        // fresh Dirichlet sample is mixed in, with a new root's arithmetic (k_step's branch, az_tree.h)
+        if (d.add_noise) {
+            Plane occ;
+#pragma unroll
+            for (int q = 0; q < 4; q++) occ.w[q] = bX.w[q] | bO.w[q];
+            const double *nz = d.noise + (size_t)game * d.noise_stride + d.noise_off[ply];
+            if (lane < G::nn && !pl_get(occ, lane)) {
+                const int rank = lane - pl_rank(occ, lane);
+                Edge *e = rows + lane;
+                const float scaled = d.one_minus_w * e->P;
+                e->P = (float)((double)scaled + d.w_noise * nz[rank]);
+            }
+        }
+        wave_mem_sync();
+    } else if (kind != LEAF_NONE) {
         float v = 0.0f;
         if (kind == LEAF_ROOT || kind == LEAF_EXPAND) {
             float P;
@@ -167,7 +183,7 @@ __device__ __forceinline__ void step_lds(const DevState &d, int b, int lane, Edg
         ST_STAMP(13);                // backup
     }
     // ---------------- stage 2: selection (mcts.py:124-129) ----------------
-    if (!do_select) {
+    if (!do_select || rootN < carried) {          // a retained root tops its visits up to S: idle until simulation `carried`
         if (lane == 0) gs.leaf_kind = LEAF_NONE;
         return;
     }
@@ -365,15 +381,25 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
         pl = d.s_player[gb]; slast = d.s_last[gb]; netid = d.s_net[gb]; game = d.s_game[gb]; ply = d.s_ply[gb];
         bX = pl_load(d.board + (size_t)gb * 8); bO = pl_load(d.board + (size_t)gb * 8 + 4);
     }
+    // subtree reuse: a root kept from the previous ply arrives as LEAF_REUSE with its compacted rows in HBM (k_reuse)
+    const int kind0 = mine ? d.leaf_kind[gb] : LEAF_NONE;
+    const int carried = (mine && d.reuse) ? d.carried[gb] : -1;
+    const int rows0 = (mine && kind0 == LEAF_REUSE) ? d.rows_used[gb] : 0;
+    if (rows0 > 0) {
+        const Edge *src = d.edges + (size_t)gb * d.R * TG::RW;
+        Edge *dst = rows_all + (size_t)wave * d.R * PG::ROWE;
+        for (int r = 0; r < rows0; r++)
+            if (lane < PG::ROWE) dst[r * PG::ROWE + lane] = src[(size_t)r * TG::RW + lane];
+    }
     if (wave < GP && lane == 0) {
         GameLds &gs = games[wave];
-        const int kind = mine ? d.leaf_kind[gb] : LEAF_NONE;       // k_begin staged the root as the pending leaf
+        const int kind = kind0;                                    // k_begin staged the root as the pending leaf
         for (int q = 0; q < 8; q++) gs.leaf[q] = mine ? d.leaf[(size_t)gb * 8 + q] : 0ull;
         gs.leaf_last = mine ? d.leaf_last[gb] : -1;
         gs.sym = (mine && d.leaf_sym) ? d.leaf_sym[gb] : 0;          // k_begin: the root is evaluation 0
-        gs.leaf_kind = kind == LEAF_ROOT ? LEAF_ROOT : LEAF_NONE;
+        gs.leaf_kind = kind == LEAF_ROOT ? LEAF_ROOT : (kind == LEAF_REUSE ? LEAF_REUSE : LEAF_NONE);
         gs.depth = 0;
-        gs.rows_used = 0;
+        gs.rows_used = rows0;
     }
     if (tid == 0) wg_net = 0;
     __syncthreads();
@@ -521,7 +547,7 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
         if (mine && (!(AZ_SEARCH_SKIP & 2) || idx == S))
             step_lds<N, PG, SYNTH>(d, gb, lane, rows_all + (size_t)wave * d.R * PG::ROWE, path_l[wave], games[wave],
                                    logits_l + wave * PG::RW, vhid_l + wave * 64, sq_lds, idx, idx < S ? 1 : 0, pl, slast, netid,
-                                   game, ply, bX, bO, cnt, w2_lds + wave * 64, b2 KS_ARG);
+                                   game, ply, bX, bO, cnt, w2_lds + wave * 64, b2, carried KS_ARG);
         KS_STAMP(8);                 // the tree step of this wave's game (waves 0 .. GP - 1)
         __syncthreads();
         KS_STAMP(9);                 // ... and the wait for the other game's
@@ -530,12 +556,15 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
     if (mine) {
         const Edge *root = rows_all + (size_t)wave * d.R * PG::ROWE;
         Edge *out = d.edges + (size_t)gb * d.R * TG::RW;
-        if (lane < PG::ROWE) out[lane] = root[lane];
+        const int nrows = d.reuse ? games[wave].rows_used : 1;     // subtree reuse: k_reuse picks the chosen child's subtree out of the whole tree
+        for (int r = 0; r < nrows; r++)
+            if (lane < PG::ROWE) out[(size_t)r * TG::RW + lane] = root[r * PG::ROWE + lane];
         if (lane == 0) {
             d.rows_used[gb] = games[wave].rows_used;
             d.leaf_kind[gb] = LEAF_NONE;
             unsigned long long *c = d.cnt + (size_t)gb * CNT_STRIDE;
             c[0] += cnt[0]; c[1] += cnt[1]; c[2] += cnt[2]; c[3] += cnt[3];
+            c[4] += kind0 == LEAF_REUSE ? 1ull : 0ull;
             c[6] += cache_lookups; c[7] += cache_hits;
         }
     }

@@ -52,12 +52,14 @@ def test_subtree_reuse_synthetic_evaluator_vs_oracle(n, k, S, G, slots):
 @pytest.mark.parametrize("split", ["0", "1000000"])
 def test_subtree_reuse_real_net_vs_oracle(split, monkeypatch):
     monkeypatch.setenv("AZ_SPLIT_MAX", split)
+    monkeypatch.setenv("AZ_PERSIST", "0" if split == "0" else "1")     # once on the lock-step pipeline, once in the persistent kernel
     n, k, S, G = 5, 4, 50, 5
     sd = weights_from_fixture(5, "ckpt_saved")                         # a trained net: peaked priors, deep reuse
     e = az.Engine(n, k, S, 3, log_table=orc.numpy_log_table(S))
     e.load_weights(sd, 0)
     e.set_subtree_reuse(True)
     c = e.selfplay(G, seed0=77)
+    assert (e.persistent() > 0) == (split != "0")      # round 3: the LDS-tree kernel loads the retained rows and writes the whole tree back
     tot = _compare_games(e, orc.Oracle(n, k, S, reuse=True), orc.Net(n, sd), n, G, 77)
     assert (c["expansions"], c["root_evals"]) == (tot["expansions"], tot["root_evals"])
     e.close()
