@@ -150,12 +150,15 @@ template <int GP, bool SY>
 int search_prepare_t(int S)
 {
     if constexpr (HAS_SEARCH) {
-        const void *fn = reinterpret_cast<const void *>(&k_search<N, GP, SY>);
-        hipFuncAttributes at;
-        if (hipFuncGetAttributes(&at, fn) != hipSuccess) return 0;
         const size_t dyn = (size_t)GP * (S + 1) * N * N * sizeof(Edge);
-        if (at.sharedSizeBytes + dyn > 160u * 1024u) return 0;
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return 0;
+        const void *fns[2] = {reinterpret_cast<const void *>(&k_search<N, GP, SY, false>),
+                              reinterpret_cast<const void *>(&k_search<N, GP, SY, GP == 2 && !SY>)};     // [1]: the tile-subset variant (search_t)
+        for (const void *fn : fns) {
+            hipFuncAttributes at;
+            if (hipFuncGetAttributes(&at, fn) != hipSuccess) return 0;
+            if (at.sharedSizeBytes + dyn > 160u * 1024u) return 0;
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return 0;
+        }
         return 1;
     } else {
         return 0;
@@ -179,9 +182,11 @@ void search_t(const LaunchCtx &c)
         dim3 g((c.d.B + GP - 1) / GP), b(AZ_NW * 64);
         const size_t dyn = (size_t)GP * c.d.R * N * N * sizeof(Edge);
         if (c.synthetic)
-            hipLaunchKernelGGL((k_search<N, GP, true>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1], c.dbg);
+            hipLaunchKernelGGL((k_search<N, GP, true, false>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1], c.dbg);
+        else if (GP == 2 && (c.d.cache || c.d.reuse))      // many iterations with one game waiting for the net: compute its tiles only
+            hipLaunchKernelGGL((k_search<N, GP, false, GP == 2>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1], c.dbg);
         else
-            hipLaunchKernelGGL((k_search<N, GP, false>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1], c.dbg);
+            hipLaunchKernelGGL((k_search<N, GP, false, false>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1], c.dbg);
     }
 }
 

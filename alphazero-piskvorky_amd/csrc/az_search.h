@@ -266,7 +266,8 @@ __device__ __forceinline__ FcPre<NG> fc_prefetch(const NetWeights &w, int wave, 
     return r;
 }
 template <class PG, class NG>
-__device__ __forceinline__ void fc_mfma(const FcPre<NG> &pre, const float *featl, float *logits_l, float *vhid_l, int wave, int lane)
+__device__ __forceinline__ void fc_mfma(const FcPre<NG> &pre, const float *featl, float *logits_l, float *vhid_l, int wave, int lane,
+                                        unsigned need)      // need: bit g = game g waits for this evaluation (the others' rows are left alone)
 {
     const int tile = wave;
     if (tile >= NG::NTP + 4) return;
@@ -297,7 +298,7 @@ __device__ __forceinline__ void fc_mfma(const FcPre<NG> &pre, const float *featl
 #pragma unroll
     for (int rg = 0; rg < 4; rg++) {
         const int g = q * 4 + rg;                      // board row of this accumulator register
-        if (g < PG::G) {
+        if (g < PG::G && ((need >> g) & 1u)) {
             const float r = (acc[0][rg] + acc[1][rg]) + (acc[2][rg] + acc[3][rg]);
             if (is_pol) {
                 const int j = tile * 16 + r16;
@@ -313,7 +314,10 @@ __device__ __forceinline__ void fc_mfma(const FcPre<NG> &pre, const float *featl
 
 // One workgroup per CU (the LDS footprint allows no second one), i.e. two waves per SIMD: let the compiler use the
 // registers that leaves (256 VGPRs) instead of spilling for an occupancy the kernel can never have.
-template <int N, int GP, bool SYNTH>
+// TS ("tile subsets", two games per workgroup): when only one of the games waits for the net, compute only the cell tiles that
+// hold its cells.  Its own instantiation, chosen when the evaluation cache or subtree reuse is on (then half of the iterations
+// look like that): three copies of the trunk made the default path 1.3 % slower, which has few such iterations.
+template <int N, int GP, bool SYNTH, bool TS = false>
 __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_search(DevState d, NetWeights w0, NetWeights w1, unsigned long long *dbg)
 {
     // diagnostic builds only (-DAZ_STAMPS): s_memtime spent in each phase of the loop, summed over the ply, per workgroup
@@ -420,6 +424,7 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
     KS_STAMP(0);
     for (int idx = 0; idx <= S; idx++) {
         bool any_eval = false;                 // does a game of the workgroup wait for the net?  Every thread works it out for itself.
+        unsigned need = 0u;                    // ... and which: bit g = game g
         if (!SYNTH) {
             // opt-in evaluation cache (az_set_eval_cache): the game's wave looks its pending leaf up in the table in HBM; a hit
             // puts the net's outputs for it into the LDS rows and the iteration needs no net for this game -- none at all when
@@ -443,7 +448,8 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
                 __syncthreads();
             }
 #pragma unroll
-            for (int g = 0; g < GP; g++) any_eval = any_eval || leaf_needs_net(games[g].leaf_kind);
+            for (int g = 0; g < GP; g++) need |= leaf_needs_net(games[g].leaf_kind) ? 1u << g : 0u;
+            any_eval = need != 0u;
         }
         // without a net phase (whose barriers do it otherwise) this barrier keeps a game's wave from replacing its pending leaf
         // while another wave still looks at it
@@ -474,29 +480,34 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
             }
             __syncthreads();
             KS_STAMP(2);
-            if (!(AZ_SEARCH_SKIP & 4)) {
-            conv_layer<PG, 4, 32, CONV_OUT_PACKED>(planes, inA, w.c1, w.c1b, wpos, cellof, wave, lane);
-            __syncthreads();
-            KS_STAMP(3);
-            const ConvPre<64, 8> pre3 = conv_prefetch<PG, 64, 128>(w.c3, wave, lane);    // ... conv3's while conv2 runs
-            conv_layer<PG, 32, 64, CONV_OUT_PACKED>(inA, inB, w.c2, w.c2b, wpos, cellof, wave, lane, 0, 0, PG::MT, 0, nullptr, nullptr, &pre2);
-            __syncthreads();
-            KS_STAMP(4);
-            conv_layer<PG, 64, 128, CONV_OUT3>(inB, lds, w.c3, w.c3b, wpos, cellof, wave, lane, 0, 0, PG::MT, 0, nullptr, nullptr, &pre3);
-            __syncthreads();
-            KS_STAMP(5);
-            }
-            const FcPre<NG> fpre = fc_prefetch<PG, NG>(w, wave, lane);      // the FC weights are on their way during the head convs
-            // policy_conv (128->4) and value_conv (128->2), 1x1, into the LDS feature rows
-            {
+            // The conv trunk and the head convs over the cell tiles [mt_base, mt_base + MTL).  Two games share a workgroup, and often
+            // only one of them waits for the net (the other's simulation ended on a terminal position, hit the cache, or idles under
+            // subtree reuse): then only the tiles that hold its cells are computed -- 2 of 4 for the first game at 5x5, 3 of 4 for
+            // the second.  Same chains for every cell that is computed, so nothing changes for the game that is evaluated.
+            FcPre<NG> fpre;
+            auto trunk = [&](auto mtl_c, const int mt_base) __attribute__((always_inline)) {
+                constexpr int MTL = decltype(mtl_c)::value;
+                conv_layer<PG, 4, 32, CONV_OUT_PACKED, 2, MTL>(planes, inA, w.c1, w.c1b, wpos, cellof, wave, lane, 0, mt_base, MTL);
+                __syncthreads();
+                KS_STAMP(3);
+                const ConvPre<64, 8> pre3 = conv_prefetch<PG, 64, 128>(w.c3, wave, lane);    // ... conv3's while conv2 runs
+                conv_layer<PG, 32, 64, CONV_OUT_PACKED, 4, MTL>(inA, inB, w.c2, w.c2b, wpos, cellof, wave, lane, 0, mt_base, MTL, 0, nullptr, nullptr, &pre2);
+                __syncthreads();
+                KS_STAMP(4);
+                conv_layer<PG, 64, 128, CONV_OUT3, 8, MTL>(inB, lds, w.c3, w.c3b, wpos, cellof, wave, lane, 0, mt_base, MTL, 0, nullptr, nullptr, &pre3);
+                __syncthreads();
+                KS_STAMP(5);
+                fpre = fc_prefetch<PG, NG>(w, wave, lane);      // the FC weights are on their way during the head convs
+                // policy_conv (128->4) and value_conv (128->2), 1x1, into the LDS feature rows
                 const int q = lane >> 4, r16 = lane & 15;
                 const float4 *wp4 = hd_lds + lane;
                 float hb[4];
 #pragma unroll
                 for (int rg = 0; rg < 4; rg++) hb[rg] = (q * 4 + rg) < 6 ? hdb_lds[q * 4 + rg] : 0.0f;
-                for (int mt = wave; mt < PG::MT; mt += AZ_NW) {
+                for (int lt = wave; lt < MTL; lt += AZ_NW) {
+                    const int mt = mt_base + lt;
                     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                    const float *ip = lds + q * PG::CS3 + mt * 16 + r16;
+                    const float *ip = lds + q * PG::CS3 + (MTL < PG::MT ? lt : mt) * 16 + r16;     // a subset's conv3 image counts its columns from its first tile
 #pragma unroll
                     for (int s4 = 0; s4 < 8; s4++) {
                         const float4 bq = wp4[s4 * 64];
@@ -518,6 +529,14 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
                         }
                     }
                 }
+            };
+            constexpr int TILES_A = (PG::nn + 15) / 16, BASE_B = PG::nn / 16, TILES_B = PG::MT - BASE_B;     // tiles of game 0 / of game 1
+            if constexpr (TS && GP == 2 && TILES_A < PG::MT && TILES_B < PG::MT && !(AZ_SEARCH_SKIP & 4)) {
+                if (need == 1u) trunk(std::integral_constant<int, TILES_A>{}, 0);
+                else if (need == 2u) trunk(std::integral_constant<int, TILES_B>{}, BASE_B);
+                else trunk(std::integral_constant<int, PG::MT>{}, 0);
+            } else {
+                trunk(std::integral_constant<int, PG::MT>{}, 0);
             }
             __syncthreads();
             KS_STAMP(6);
@@ -525,10 +544,10 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
                 float4 *z = reinterpret_cast<float4 *>(lds);
                 for (int i = tid; i < (96 * PG::CS) / 4; i += NTH) z[i] = float4{0.f, 0.f, 0.f, 0.f};
             }
-            if (!(AZ_SEARCH_SKIP & 1)) fc_mfma<PG, NG>(fpre, featl, logits_l, vhid_l, wave, lane);
+            if (!(AZ_SEARCH_SKIP & 1)) fc_mfma<PG, NG>(fpre, featl, logits_l, vhid_l, wave, lane, need);
             __syncthreads();
             KS_STAMP(7);
-            // a fresh evaluation is remembered (a game that hit had its rows recomputed beside its sibling's: the same floats)
+            // a fresh evaluation is remembered (the rows of a game that hit are the cache's: the FC layers leave them alone)
             if (d.cache && mine && leaf_needs_net(games[wave].leaf_kind)) {
                 const GameLds &gs = games[wave];
                 Plane lme, lopp;
