@@ -943,11 +943,11 @@ static int episode_begin(az_engine *e, const EpisodeSpec &sp)
     });
     // persistent search kernel: plain net or synthetic evaluator, the reference's sequential search, trees that fit into LDS
     e->persist_gp = 0;
-    if (e->persist_allowed && e->cfg.model == AZ_MODEL_PLAIN && !e->vl_kernel && e->trunk_mode == AZ_TRUNK_F32) {
+    if (e->persist_allowed && !e->vl_kernel && e->trunk_mode == AZ_TRUNK_F32) {
         const int synth = e->cfg.eval_kind == AZ_EVAL_SYNTHETIC ? 1 : 0;
         const int S = e->cfg.num_simulations;
-        if (!sp.arena && !sp.preset && e->ops->search_prepare(S, 2, synth)) e->persist_gp = 2;
-        else if (e->ops->search_prepare(S, 1, synth)) e->persist_gp = 1;     // arena: a workgroup's games must share one net
+        if (!sp.arena && !sp.preset && e->ops->search_prepare(S, 2, synth, e->cfg.model)) e->persist_gp = 2;
+        else if (e->ops->search_prepare(S, 1, synth, e->cfg.model)) e->persist_gp = 1;     // arena: a workgroup's games must share one net
     }
     az_engine::Run &r = e->run;
     r = az_engine::Run();

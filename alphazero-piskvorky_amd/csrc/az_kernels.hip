@@ -146,13 +146,13 @@ void root_cache(const LaunchCtx &c)
 constexpr bool HAS_SEARCH = N <= 7;      // the LDS-resident tree needs (S + 1) * n*n * 16 B per game
 constexpr bool HAS_SEARCH2 = N <= 5;     // two games per workgroup: beyond 5x5 the rows of two games never fit beside the image
 
-template <int GP, bool SY>
+template <int GP, bool SY, bool RES>
 int search_prepare_t(int S)
 {
     if constexpr (HAS_SEARCH) {
         const size_t dyn = (size_t)GP * (S + 1) * N * N * sizeof(Edge);
-        const void *fns[2] = {reinterpret_cast<const void *>(&k_search<N, GP, SY, false>),
-                              reinterpret_cast<const void *>(&k_search<N, GP, SY, GP == 2 && !SY>)};     // [1]: the tile-subset variant (search_t)
+        const void *fns[2] = {reinterpret_cast<const void *>(&k_search<N, GP, SY, false, RES>),
+                              reinterpret_cast<const void *>(&k_search<N, GP, SY, GP == 2 && !SY, RES>)};     // [1]: the tile-subset variant (search_t)
         for (const void *fn : fns) {
             hipFuncAttributes at;
             if (hipFuncGetAttributes(&at, fn) != hipSuccess) return 0;
@@ -165,13 +165,15 @@ int search_prepare_t(int S)
     }
 }
 
-int search_prepare(int S, int games, int synthetic)
+int search_prepare(int S, int games, int synthetic, int model)
 {
+    const bool res = model == 1 && !synthetic;         // the synthetic evaluator has no net: the plain kernels serve it
     if (games == 2) {
-        if constexpr (HAS_SEARCH2) return synthetic ? search_prepare_t<2, true>(S) : search_prepare_t<2, false>(S);
+        if constexpr (HAS_SEARCH2)
+            return synthetic ? search_prepare_t<2, true, false>(S) : (res ? search_prepare_t<2, false, true>(S) : search_prepare_t<2, false, false>(S));
         return 0;
     }
-    if (games == 1) return synthetic ? search_prepare_t<1, true>(S) : search_prepare_t<1, false>(S);
+    if (games == 1) return synthetic ? search_prepare_t<1, true, false>(S) : (res ? search_prepare_t<1, false, true>(S) : search_prepare_t<1, false, false>(S));
     return 0;
 }
 
@@ -181,12 +183,16 @@ void search_t(const LaunchCtx &c)
     if constexpr (HAS_SEARCH) {
         dim3 g((c.d.B + GP - 1) / GP), b(AZ_NW * 64);
         const size_t dyn = (size_t)GP * c.d.R * N * N * sizeof(Edge);
+        const bool ts = GP == 2 && (c.d.cache || c.d.reuse);      // many iterations with one game waiting for the net: compute its tiles only
         if (c.synthetic)
-            hipLaunchKernelGGL((k_search<N, GP, true, false>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1], c.dbg);
-        else if (GP == 2 && (c.d.cache || c.d.reuse))      // many iterations with one game waiting for the net: compute its tiles only
-            hipLaunchKernelGGL((k_search<N, GP, false, GP == 2>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1], c.dbg);
-        else
-            hipLaunchKernelGGL((k_search<N, GP, false, false>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1], c.dbg);
+            hipLaunchKernelGGL((k_search<N, GP, true, false, false>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1], c.dbg, NoWeights{}, NoWeights{});
+        else if (c.model == 1) {
+            if (ts) hipLaunchKernelGGL((k_search<N, GP, false, GP == 2, true>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1], c.dbg, c.rw[0], c.rw[1]);
+            else hipLaunchKernelGGL((k_search<N, GP, false, false, true>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1], c.dbg, c.rw[0], c.rw[1]);
+        } else {
+            if (ts) hipLaunchKernelGGL((k_search<N, GP, false, GP == 2, false>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1], c.dbg, NoWeights{}, NoWeights{});
+            else hipLaunchKernelGGL((k_search<N, GP, false, false, false>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1], c.dbg, NoWeights{}, NoWeights{});
+        }
     }
 }
 

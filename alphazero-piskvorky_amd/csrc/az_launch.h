@@ -32,7 +32,7 @@ struct SizeOps {
     void (*root_cache)(const LaunchCtx &);                                // evaluation-cache lookup of the root positions
     // persistent search kernel (az_search.h): prepare returns 1 when `games` games per workgroup with S simulations fit
     // into LDS on the current device (and raises the kernel's dynamic-LDS limit), 0 when this size has no such kernel
-    int (*search_prepare)(int S, int games, int synthetic);
+    int (*search_prepare)(int S, int games, int synthetic, int model);
     void (*search)(const LaunchCtx &, int games);
     void (*move)(const LaunchCtx &);
     void (*eval_tail)(const LaunchCtx &, int count, float *policy, float *value);

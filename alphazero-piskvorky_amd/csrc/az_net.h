@@ -128,6 +128,10 @@ struct ResGeo {
     static constexpr int FROW = (((PC + VC) * nn + 3) / 4) * 4;
     static constexpr int QGP = fc_chain_groups(PC * nn), QGV = fc_chain_groups(VC * nn);
     static constexpr int QGMAX = QGP > QGV ? QGP : QGV;
+    // LDS feature rows of the persistent search kernel (as NetGeo)
+    static constexpr int VOFFL = 64 * QGP;
+    static constexpr int FSTR0 = 64 * (QGP + QGV);
+    static constexpr int FSTR = FSTR0 + ((4 - (FSTR0 % 32) + 32) % 32);
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)

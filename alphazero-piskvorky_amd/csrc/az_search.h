@@ -30,7 +30,7 @@
 #define AZ_SEARCH_SKIP 0      // timing-only experiment builds (results are wrong): 1 = no FC, 2 = no tree step, 4 = no conv trunk
 #endif
 
-template <int N, int GP>
+template <int N, int GP, bool RES = false>
 struct PersistGeo {
     static constexpr int n = N, nn = N * N, PW = N + 2, PP = PW * PW;
     static constexpr int G = GP;                                   // games (boards) per workgroup
@@ -41,10 +41,11 @@ struct PersistGeo {
     // row stride of the conv3 image [co][cell]: 16 mod 32, so that the four k-rows the head convs read with one instruction
     // (channels q, q + 1, q + 2, q + 3 of a group: q x CS3 floats apart) fall into different LDS banks
     static constexpr int CS3 = up16(MR) % 32 == 0 ? up16(MR) + 16 : up16(MR);
-    static constexpr int LDSF = (96 * CS > 128 * CS3) ? 96 * CS : 128 * CS3;
+    // plain net: conv1 / conv2 outputs (32 + 64 channels) with conv3's [co][cell] image on top; ResidualBlock net: two 64-channel images
+    static constexpr int LDSF = RES ? 128 * CS : ((96 * CS > 128 * CS3) ? 96 * CS : 128 * CS3);
     static constexpr int RW = ((nn + 63) / 64) * 64;
     static constexpr int NW = AZ_NW;
-    static constexpr int PC = 4, VC = 2;
+    static constexpr int PC = RES ? 2 : 4, VC = RES ? 1 : 2;
     static constexpr int FROW = (((PC + VC) * nn + 3) / 4) * 4;
     static constexpr int PATH = nn + 1;
     static constexpr int ROWE = nn;                                // edges per tree row in LDS (no padding to 64)
@@ -317,8 +318,13 @@ __device__ __forceinline__ void fc_mfma(const FcPre<NG> &pre, const float *featl
 // TS ("tile subsets", two games per workgroup): when only one of the games waits for the net, compute only the cell tiles that
 // hold its cells.  Its own instantiation, chosen when the evaluation cache or subtree reuse is on (then half of the iterations
 // look like that): three copies of the trunk made the default path 1.3 % slower, which has few such iterations.
-template <int N, int GP, bool SYNTH, bool TS = false>
-__global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_search(DevState d, NetWeights w0, NetWeights w1, unsigned long long *dbg)
+// RES: the ResidualBlock net (stem + 3 blocks on two 64-channel images, 2 + 1 head channels; k_trunk_res): r0 / r1 hold its conv
+// weights, w0 / w1 only the FC layers'.  The reference's trained ResidualBlock checkpoints are 5x5 nets.
+struct NoWeights { };
+template <int N, int GP, bool SYNTH, bool TS = false, bool RES = false>
+__global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_search(DevState d, NetWeights w0, NetWeights w1, unsigned long long *dbg,
+                                                                                                  std::conditional_t<RES, ResWeights, NoWeights> r0,
+                                                                                                  std::conditional_t<RES, ResWeights, NoWeights> r1)
 {
     // diagnostic builds only (-DAZ_STAMPS): s_memtime spent in each phase of the loop, summed over the ply, per workgroup
     // (slots 0-9: the loop's phases on waves 0 and 1; 10-18: inside the tree step, see step_lds)
@@ -330,9 +336,11 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
 #else
 #define KS_STAMP(i) do { } while (0)
 #endif
-    typedef PersistGeo<N, GP> PG;
-    typedef NetGeo<N> NG;
+    typedef PersistGeo<N, GP, RES> PG;
+    typedef std::conditional_t<RES, ResGeo<N>, NetGeo<N>> NG;
     typedef TreeGeo<N> TG;
+    constexpr int HK = RES ? 4 : 8;                      // k-groups of 16 channels the head convs run over (64 / 128 input channels)
+    constexpr int HC = PG::PC + PG::VC;                  // head channels
     constexpr int NTH = AZ_NW * 64;
     static_assert(NTH == 512, "hd_lds is filled by one float4 per thread");
     __shared__ __attribute__((aligned(16))) float lds[PG::LDSF];
@@ -368,7 +376,7 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
     // conv3's [co][cell] image on top of them; the workgroup clears that again while the FC phase waits for its MFMA chains.
     {
         float4 *z = reinterpret_cast<float4 *>(lds);
-        for (int i = tid; i < (96 * PG::CS) / 4; i += NTH) z[i] = float4{0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < (RES ? PG::LDSF : 96 * PG::CS) / 4; i += NTH) z[i] = float4{0.f, 0.f, 0.f, 0.f};
     }
     // tile tables (constant over the ply)
     for (int m = tid; m < PG::MR; m += NTH) {
@@ -411,8 +419,13 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
     __syncthreads();
     if (!SYNTH) {                      // the head convs' weights stay in LDS for the ply (their L2 round trip sat between conv3 and the heads)
         const bool o = wg_net != 0;
-        hd_lds[tid] = reinterpret_cast<const float4 *>(o ? w1.hd : w0.hd)[tid];          // 8 k-groups x 64 lanes = the 512 threads
-        if (tid < 8) hdb_lds[tid] = tid < 6 ? (o ? w1.hdb : w0.hdb)[tid] : 0.0f;
+        if constexpr (RES) {
+            if (tid < HK * 64) hd_lds[tid] = reinterpret_cast<const float4 *>(o ? r1.hd : r0.hd)[tid];
+            if (tid < 8) hdb_lds[tid] = tid < HC ? (o ? r1.hdb : r0.hdb)[tid] : 0.0f;
+        } else {
+            hd_lds[tid] = reinterpret_cast<const float4 *>(o ? w1.hd : w0.hd)[tid];          // 8 k-groups x 64 lanes = the 512 threads
+            if (tid < 8) hdb_lds[tid] = tid < HC ? (o ? w1.hdb : w0.hdb)[tid] : 0.0f;
+        }
     }
     unsigned long long cnt[4] = {0ull, 0ull, 0ull, 0ull};
     unsigned long long cache_lookups = 0ull, cache_hits = 0ull;
@@ -463,7 +476,8 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
                 w.pf = o ? w1.pf : w0.pf; w.vf = o ? w1.vf : w0.vf; w.c1b = o ? w1.c1b : w0.c1b; w.c2b = o ? w1.c2b : w0.c2b;
                 w.c3b = o ? w1.c3b : w0.c3b; w.hdb = o ? w1.hdb : w0.hdb; w.pfb = o ? w1.pfb : w0.pfb; w.vfb = o ? w1.vfb : w0.vfb;
             }
-            const ConvPre<32, 4> pre2 = conv_prefetch<PG, 32, 64>(w.c2, wave, lane);     // conv2's first weights: asked for three phases early
+            ConvPre<32, 4> pre2;
+            if constexpr (!RES) pre2 = conv_prefetch<PG, 32, 64>(w.c2, wave, lane);     // conv2's first weights: asked for three phases early
             // ---- leaf encode + conv trunk, as trunk_group (az_net.h) on the LDS-resident leaves ----
             for (int i = tid; i < 3 * PG::CS; i += NTH) {       // games.py:86-129 encode: every position of the three planes, padding = 0
                 const int c = i / PG::CS, pos = i - c * PG::CS;
@@ -487,44 +501,79 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
             FcPre<NG> fpre;
             auto trunk = [&](auto mtl_c, const int mt_base) __attribute__((always_inline)) {
                 constexpr int MTL = decltype(mtl_c)::value;
-                conv_layer<PG, 4, 32, CONV_OUT_PACKED, 2, MTL>(planes, inA, w.c1, w.c1b, wpos, cellof, wave, lane, 0, mt_base, MTL);
-                __syncthreads();
-                KS_STAMP(3);
-                const ConvPre<64, 8> pre3 = conv_prefetch<PG, 64, 128>(w.c3, wave, lane);    // ... conv3's while conv2 runs
-                conv_layer<PG, 32, 64, CONV_OUT_PACKED, 4, MTL>(inA, inB, w.c2, w.c2b, wpos, cellof, wave, lane, 0, mt_base, MTL, 0, nullptr, nullptr, &pre2);
-                __syncthreads();
-                KS_STAMP(4);
-                conv_layer<PG, 64, 128, CONV_OUT3, 8, MTL>(inB, lds, w.c3, w.c3b, wpos, cellof, wave, lane, 0, mt_base, MTL, 0, nullptr, nullptr, &pre3);
-                __syncthreads();
-                KS_STAMP(5);
+                if constexpr (RES) {
+                    // stem + three residual blocks on the two 64-channel images, as k_trunk_res (az_net.h); the images' padding ring is
+                    // never written, so it needs no clearing between evaluations
+                    const bool o = wg_net != 0;
+                    float *A = lds, *B = lds + 64 * PG::CS;
+                    conv_layer<PG, 4, 64, CONV_OUT_PACKED, 4, MTL>(planes, A, o ? r1.stem : r0.stem, o ? r1.stemb : r0.stemb, wpos, cellof, wave, lane, 0, mt_base, MTL);
+                    __syncthreads();
+                    KS_STAMP(3);
+#pragma unroll 1
+                    for (int blk = 0; blk < 3; blk++) {        // (asking for a conv's first weights a layer early measured equal here: not done)
+                        conv_layer<PG, 64, 64, CONV_OUT_PACKED, 4, MTL>(A, B, o ? r1.blk[2 * blk] : r0.blk[2 * blk], o ? r1.blkb[2 * blk] : r0.blkb[2 * blk], wpos,
+                                                                        cellof, wave, lane, 0, mt_base, MTL);
+                        __syncthreads();
+                        conv_layer<PG, 64, 64, CONV_OUT_RESIDUAL, 4, MTL>(B, A, o ? r1.blk[2 * blk + 1] : r0.blk[2 * blk + 1],
+                                                                          o ? r1.blkb[2 * blk + 1] : r0.blkb[2 * blk + 1], wpos, cellof, wave, lane, 0, mt_base, MTL);
+                        __syncthreads();
+                    }
+                    KS_STAMP(5);
+                } else {
+                    conv_layer<PG, 4, 32, CONV_OUT_PACKED, 2, MTL>(planes, inA, w.c1, w.c1b, wpos, cellof, wave, lane, 0, mt_base, MTL);
+                    __syncthreads();
+                    KS_STAMP(3);
+                    const ConvPre<64, 8> pre3 = conv_prefetch<PG, 64, 128>(w.c3, wave, lane);    // ... conv3's while conv2 runs
+                    conv_layer<PG, 32, 64, CONV_OUT_PACKED, 4, MTL>(inA, inB, w.c2, w.c2b, wpos, cellof, wave, lane, 0, mt_base, MTL, 0, nullptr, nullptr, &pre2);
+                    __syncthreads();
+                    KS_STAMP(4);
+                    conv_layer<PG, 64, 128, CONV_OUT3, 8, MTL>(inB, lds, w.c3, w.c3b, wpos, cellof, wave, lane, 0, mt_base, MTL, 0, nullptr, nullptr, &pre3);
+                    __syncthreads();
+                    KS_STAMP(5);
+                }
                 fpre = fc_prefetch<PG, NG>(w, wave, lane);      // the FC weights are on their way during the head convs
-                // policy_conv (128->4) and value_conv (128->2), 1x1, into the LDS feature rows
+                // policy_conv and value_conv, 1x1 (plain: 128 -> 4 + 2 over conv3's [co][cell] image; ResidualBlock: 64 -> 2 + 1 over the
+                // packed trunk image), into the LDS feature rows
                 const int q = lane >> 4, r16 = lane & 15;
                 const float4 *wp4 = hd_lds + lane;
                 float hb[4];
 #pragma unroll
-                for (int rg = 0; rg < 4; rg++) hb[rg] = (q * 4 + rg) < 6 ? hdb_lds[q * 4 + rg] : 0.0f;
+                for (int rg = 0; rg < 4; rg++) hb[rg] = (q * 4 + rg) < HC ? hdb_lds[q * 4 + rg] : 0.0f;
                 for (int lt = wave; lt < MTL; lt += AZ_NW) {
                     const int mt = mt_base + lt;
                     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                    const float *ip = lds + q * PG::CS3 + (MTL < PG::MT ? lt : mt) * 16 + r16;     // a subset's conv3 image counts its columns from its first tile
+                    if constexpr (RES) {
+                        const float4 *in4 = reinterpret_cast<const float4 *>(lds);
+                        const int base = q * PG::CS + (int)wpos[mt * 16 + r16];
 #pragma unroll
-                    for (int s4 = 0; s4 < 8; s4++) {
-                        const float4 bq = wp4[s4 * 64];
-                        acc = mfma4(bq.x, ip[(s4 * 16 + 0) * PG::CS3], acc);
-                        acc = mfma4(bq.y, ip[(s4 * 16 + 4) * PG::CS3], acc);
-                        acc = mfma4(bq.z, ip[(s4 * 16 + 8) * PG::CS3], acc);
-                        acc = mfma4(bq.w, ip[(s4 * 16 + 12) * PG::CS3], acc);
+                        for (int cg = 0; cg < HK; cg++) {
+                            const float4 a = in4[base + cg * 4 * PG::CS];
+                            const float4 wq = wp4[cg * 64];
+                            acc = mfma4(wq.x, a.x, acc);
+                            acc = mfma4(wq.y, a.y, acc);
+                            acc = mfma4(wq.z, a.z, acc);
+                            acc = mfma4(wq.w, a.w, acc);
+                        }
+                    } else {
+                        const float *ip = lds + q * PG::CS3 + (MTL < PG::MT ? lt : mt) * 16 + r16;     // a subset's conv3 image counts its columns from its first tile
+#pragma unroll
+                        for (int s4 = 0; s4 < HK; s4++) {
+                            const float4 bq = wp4[s4 * 64];
+                            acc = mfma4(bq.x, ip[(s4 * 16 + 0) * PG::CS3], acc);
+                            acc = mfma4(bq.y, ip[(s4 * 16 + 4) * PG::CS3], acc);
+                            acc = mfma4(bq.z, ip[(s4 * 16 + 8) * PG::CS3], acc);
+                            acc = mfma4(bq.w, ip[(s4 * 16 + 12) * PG::CS3], acc);
+                        }
                     }
                     const int cell = cellof[mt * 16 + r16];
                     if (cell != 0xFFFF) {
                         const int g = cell / PG::nn, p = cell - g * PG::nn;
 #pragma unroll
                         for (int rg = 0; rg < 4; rg++) {
-                            const int j = q * 4 + rg;     // head channel: 0-3 policy_conv, 4-5 value_conv (net.py:64,69 flatten order)
-                            if (j < 6) {
+                            const int j = q * 4 + rg;     // head channel: policy_conv's, then value_conv's (net.py:64,69 flatten order)
+                            if (j < HC) {
                                 float v = acc[rg] + hb[rg];
-                                featl[g * NG::FSTR + (j < 4 ? j * PG::nn : NG::VOFFL + (j - 4) * PG::nn) + p] = v > 0.0f ? v : 0.0f;
+                                featl[g * NG::FSTR + (j < PG::PC ? j * PG::nn : NG::VOFFL + (j - PG::PC) * PG::nn) + p] = v > 0.0f ? v : 0.0f;
                             }
                         }
                     }
@@ -540,7 +589,7 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
             }
             __syncthreads();
             KS_STAMP(6);
-            {
+            if constexpr (!RES) {
                 float4 *z = reinterpret_cast<float4 *>(lds);
                 for (int i = tid; i < (96 * PG::CS) / 4; i += NTH) z[i] = float4{0.f, 0.f, 0.f, 0.f};
             }
