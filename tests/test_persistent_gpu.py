@@ -15,9 +15,9 @@ from alphazero_piskvorky_amd.weights import synthetic_state_dict
 WORK = ("games", "plies", "records", "simulations", "expansions", "root_evals", "terminal_hits", "depth_sum", "trunk_boards")
 
 
-def _run(monkeypatch, persist, n, k, S, slots, G, synthetic, sd, cut=0, arena_games=0, sd2=None):
+def _run(monkeypatch, persist, n, k, S, slots, G, synthetic, sd, cut=0, arena_games=0, sd2=None, model="plain"):
     monkeypatch.setenv("AZ_PERSIST", persist)
-    e = az.Engine(n, k, S, slots, synthetic=synthetic, log_table=orc.numpy_log_table(S))
+    e = az.Engine(n, k, S, slots, synthetic=synthetic, log_table=orc.numpy_log_table(S), model=model)
     if not synthetic:
         e.load_weights(sd, 0)
         e.load_weights(sd2 if sd2 is not None else sd, 1)
@@ -53,6 +53,25 @@ def test_persistent_kernel_equals_the_lockstep_pipeline(monkeypatch, n, k, S, sl
     assert a["search"]["action"] == b["search"]["action"]
     # one launch per ply instead of three per simulation: the lock-step pipeline counts (S + 1) trunk launches per ply
     assert synthetic or b["c"]["trunk_launches"] * (S + 1) == a["c"]["trunk_launches"]
+
+
+@pytest.mark.parametrize("n,k,S,slots,G", [(5, 4, 60, 7, 15), (7, 5, 30, 4, 5), (4, 3, 20, 3, 6)])
+def test_persistent_kernel_residual_block_net_equals_the_lockstep_pipeline(monkeypatch, n, k, S, slots, G):
+    """Round 3: the persistent kernel runs the ResidualBlock net too (stem + 3 blocks on two 64-channel LDS images).  Episodes with
+    refill, the two-net arena and a single search: identical to k_trunk_res + k_fc + k_step."""
+    from alphazero_piskvorky_amd.weights import synthetic_resnet_state_dict
+    sd, sd2 = synthetic_resnet_state_dict(n), synthetic_resnet_state_dict(n, 2)
+    a = _run(monkeypatch, "0", n, k, S, slots, G, False, sd, arena_games=4, sd2=sd2, model="resnet")
+    b = _run(monkeypatch, "1", n, k, S, slots, G, False, sd, arena_games=4, sd2=sd2, model="resnet")
+    for key in a["rec"]:
+        assert np.array_equal(a["rec"][key], b["rec"][key]), key
+    assert np.array_equal(a["games"][0], b["games"][0]) and np.array_equal(a["games"][1], b["games"][1])
+    for key in WORK:
+        assert a["c"][key] == b["c"][key], key
+    assert np.array_equal(a["arena"]["actions"], b["arena"]["actions"]) and np.array_equal(a["arena"]["results"], b["arena"]["results"])
+    for key in ("N", "W", "P", "pi"):
+        assert np.array_equal(a["search"][key], b["search"][key]), key
+    assert b["c"]["trunk_launches"] * (S + 1) == a["c"]["trunk_launches"]        # one launch per ply: it did run
 
 
 def test_persistent_kernel_full_5x5_games_vs_oracle(monkeypatch):
