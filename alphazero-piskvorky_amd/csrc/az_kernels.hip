@@ -183,7 +183,8 @@ void search_t(const LaunchCtx &c)
     if constexpr (HAS_SEARCH) {
         dim3 g((c.d.B + GP - 1) / GP), b(AZ_NW * 64);
         const size_t dyn = (size_t)GP * c.d.R * N * N * sizeof(Edge);
-        const bool ts = GP == 2 && (c.d.cache || c.d.reuse);      // many iterations with one game waiting for the net: compute its tiles only
+        static const int ts_env = getenv("AZ_SEARCH_TS") ? atoi(getenv("AZ_SEARCH_TS")) : -1;      // experiment: force the variant
+        const bool ts = GP == 2 && (ts_env >= 0 ? ts_env != 0 : (c.d.cache || c.d.reuse));      // many iterations with one game waiting for the net: compute its tiles only
         if (c.synthetic)
             hipLaunchKernelGGL((k_search<N, GP, true, false, false>), g, b, dyn, c.stream, c.d, c.w[0], c.w[1], c.dbg, NoWeights{}, NoWeights{});
         else if (c.model == 1) {
