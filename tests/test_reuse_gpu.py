@@ -87,3 +87,29 @@ def test_subtree_reuse_argument_checks():
         e.set_subtree_reuse(True)                                      # not while an episode is open
     e.selfplay_end()
     e.close()
+
+
+@pytest.mark.parametrize("n,k,S,G,slots,cut", [(5, 4, 50, 8, 4, 0), (9, 5, 30, 4, 3, 8)])
+def test_subtree_reuse_residual_block_net_vs_oracle(n, k, S, G, slots, cut):
+    """The ResidualBlock net with subtree reuse: in the persistent kernel at 5x5 (round 3), on the lock-step pipeline at 9x9."""
+    from alphazero_piskvorky_amd.net import fold_resnet_state_dict
+    from alphazero_piskvorky_amd.weights import synthetic_resnet_state_dict
+    sd = synthetic_resnet_state_dict(n)
+    onet = orc.Net(n, resnet_tensors=fold_resnet_state_dict(sd))
+    e = az.Engine(n, k, S, slots, model="resnet", log_table=orc.numpy_log_table(S))
+    e.load_weights(sd, 0)
+    e.set_subtree_reuse(True)
+    c = e.selfplay(G, seed0=610, max_plies=cut)
+    assert (e.persistent() > 0) == (n <= 7)
+    rec = e.records(); nply, res = e.games()
+    e.close()
+    o = orc.Oracle(n, k, S, reuse=True)
+    off = 0
+    for g in range(G):
+        noise, us = orc.selfplay_tape(610 + g, n, maxply=cut or None)
+        r = o.selfplay_game(onet, noise, us, maxply=cut or None)
+        Lg = int(nply[g]); sl = slice(off, off + Lg)
+        assert Lg == r["nply"], f"game {g}"
+        for key in ("actions", "boards", "visits", "pis"):
+            assert np.array_equal(rec[key][sl], r[key]), f"game {g}: {key}"
+        off += Lg
