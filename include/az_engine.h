@@ -351,9 +351,9 @@ int az_get_lanes(const az_engine *e);
 /* Which kernels ran the searches of the last (or the open) episode: 0 = the lock-step pipeline, one conv-trunk, FC and
  * tree launch per evaluation batch; g > 0 = the persistent search kernel (csrc/az_search.h), one launch per ply with g
  * games per workgroup and their trees resident in LDS.  The library picks the persistent kernel by itself whenever it
- * applies -- boards up to 7x7 whose (num_simulations + 1) tree rows fit into LDS, GomokuNet or the synthetic evaluator,
- * none of the opt-in search upgrades -- because its results are bit-identical; AZ_PERSIST=0 in the environment keeps the
- * lock-step pipeline. */
+ * applies -- boards up to 7x7 whose (num_simulations + 1) tree rows fit into LDS, either net or the synthetic evaluator,
+ * float32 trunk, no virtual-loss batching (the evaluation cache, subtree reuse and the leaf symmetry it knows) -- because
+ * its results are bit-identical; AZ_PERSIST=0 in the environment keeps the lock-step pipeline. */
 int az_get_persistent(const az_engine *e);
 
 #ifdef __cplusplus
