@@ -27,7 +27,7 @@
 #define KS_ARG
 #endif
 #ifndef AZ_SEARCH_SKIP
-#define AZ_SEARCH_SKIP 0      // timing-only experiment builds (results are wrong): 1 = no FC, 2 = no tree step, 4 = no conv trunk
+#define AZ_SEARCH_SKIP 0      // timing-only experiment builds (results are wrong): 1 = no FC, 2 = no tree step
 #endif
 
 template <int N, int GP, bool RES = false>
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(AZ_NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2
                 }
             };
             constexpr int TILES_A = (PG::nn + 15) / 16, BASE_B = PG::nn / 16, TILES_B = PG::MT - BASE_B;     // tiles of game 0 / of game 1
-            if constexpr (TS && GP == 2 && TILES_A < PG::MT && TILES_B < PG::MT && !(AZ_SEARCH_SKIP & 4)) {
+            if constexpr (TS && GP == 2 && TILES_A < PG::MT && TILES_B < PG::MT) {
                 if (need == 1u) trunk(std::integral_constant<int, TILES_A>{}, 0);
                 else if (need == 2u) trunk(std::integral_constant<int, TILES_B>{}, BASE_B);
                 else trunk(std::integral_constant<int, PG::MT>{}, 0);
